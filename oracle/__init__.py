@@ -1,0 +1,292 @@
+"""ctypes front end of the CPU oracle (``oracle/unflow_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg.  ``unflow_amd`` never imports it.
+
+All functions take and return C-contiguous float32 numpy arrays in the
+reference's layouts (correlation NCHW, everything else NHWC).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libunflow_oracle.so")
+
+_ERRORS = {
+    1: "kernel_size must be odd",                                   # ops/correlation_op.h:16-17
+    2: "Input shapes have to be the same",                          # ops/correlation_op.cc:47-48
+    3: "Invalid correlation settings",                              # ops/correlation_op.cc:60-61
+    4: "Input height and width must be divisible by scale",         # ops/downsample_op.cc:37-40
+    5: "invalid argument",
+}
+
+
+def build(force=False):
+    """Compile the oracle with gcc (``make -C oracle``)."""
+    src = os.path.join(_HERE, "unflow_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libunflow_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        L.oracle_charbonnier_fwd.restype = ctypes.c_double
+        L.oracle_ternary_loss_fwd.restype = ctypes.c_double
+        L.oracle_num_threads.restype = ctypes.c_int
+        L.oracle_border_size.restype = ctypes.c_int
+        L.oracle_border_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_float]
+        _lib = L
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    if a is None:
+        return ctypes.c_void_p(0)
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _check(rc):
+    if rc != 0:
+        raise ValueError(_ERRORS.get(rc, "oracle error %d" % rc))
+
+
+def num_threads():
+    return lib().oracle_num_threads()
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))
+
+
+# --------------------------------------------------------------------------- correlation
+def correlation_geometry(H, W, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
+    dims = (ctypes.c_int * 5)()
+    _check(lib().oracle_correlation_geometry(H, W, kernel_size, max_displacement, pad, stride_1,
+                                             stride_2, dims))
+    return dict(out_channels=dims[0], out_height=dims[1], out_width=dims[2],
+                padded_height=dims[3], padded_width=dims[4])
+
+
+def correlation(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
+    """Returns (correlation, padded_0, padded_1) like the 3-output reference op."""
+    first, second = _f32(first), _f32(second)
+    if first.shape != second.shape:
+        raise ValueError(_ERRORS[2])
+    B, C, H, W = first.shape
+    g = correlation_geometry(H, W, kernel_size, max_displacement, pad, stride_1, stride_2)
+    out = np.empty((B, g["out_channels"], g["out_height"], g["out_width"]), np.float32)
+    p0 = np.empty((B, g["padded_height"], g["padded_width"], C), np.float32)
+    p1 = np.empty_like(p0)
+    _check(lib().oracle_correlation_fwd(_p(first), _p(second), _p(out), _p(p0), _p(p1), B, C, H, W,
+                                        kernel_size, max_displacement, pad, stride_1, stride_2))
+    return out, p0, p1
+
+
+def correlation_grad(in_grad, in0, in1, padded0, padded1, kernel_size=1, max_displacement=20,
+                     pad=20, stride_1=1, stride_2=2):
+    in_grad, padded0, padded1 = _f32(in_grad), _f32(padded0), _f32(padded1)
+    B, C, H, W = in0.shape
+    g0 = np.empty((B, C, H, W), np.float32)
+    g1 = np.empty((B, C, H, W), np.float32)
+    _check(lib().oracle_correlation_bwd(_p(in_grad), _p(padded0), _p(padded1), _p(g0), _p(g1), B, C,
+                                        H, W, kernel_size, max_displacement, pad, stride_1, stride_2))
+    return g0, g1
+
+
+# --------------------------------------------------------------------------- warps
+def backward_warp(images, flows):
+    images, flows = _f32(images), _f32(flows)
+    B, H, W, C = images.shape
+    out = np.empty_like(images)
+    lib().oracle_backward_warp_fwd(_p(images), _p(flows), _p(out), B, H, W, C)
+    return out
+
+
+def backward_warp_grad(grads, images, flows):
+    grads, images, flows = _f32(grads), _f32(images), _f32(flows)
+    B, H, W, C = images.shape
+    out = np.empty((B, H, W, 2), np.float32)
+    lib().oracle_backward_warp_bwd(_p(grads), _p(images), _p(flows), _p(out), B, H, W, C)
+    return out
+
+
+def forward_warp(flows):
+    flows = _f32(flows)
+    B, H, W, _ = flows.shape
+    out = np.empty((B, H, W, 1), np.float32)
+    lib().oracle_forward_warp_fwd(_p(flows), _p(out), B, H, W)
+    return out
+
+
+def forward_warp_grad(grads, flows):
+    grads, flows = _f32(grads), _f32(flows)
+    B, H, W, _ = flows.shape
+    out = np.empty((B, H, W, 2), np.float32)
+    lib().oracle_forward_warp_bwd(_p(grads), _p(flows), _p(out), B, H, W)
+    return out
+
+
+def downsample(images, scale):
+    images = _f32(images)
+    B, H, W, C = images.shape
+    if scale <= 0 or H % scale or W % scale:
+        raise ValueError(_ERRORS[4])
+    out = np.empty((B, H // scale, W // scale, C), np.float32)
+    _check(lib().oracle_downsample(_p(images), _p(out), B, H, W, C, scale))
+    return out
+
+
+def image_warp(im, flow):
+    im, flow = _f32(im), _f32(flow)
+    B, H, W, C = im.shape
+    out = np.empty_like(im)
+    lib().oracle_image_warp_fwd(_p(im), _p(flow), _p(out), B, H, W, C)
+    return out
+
+
+def image_warp_grad(grad, im, flow, want_im=True, want_flow=True):
+    grad, im, flow = _f32(grad), _f32(im), _f32(flow)
+    B, H, W, C = im.shape
+    d_im = np.empty_like(im) if want_im else None
+    d_flow = np.empty((B, H, W, 2), np.float32) if want_flow else None
+    lib().oracle_image_warp_bwd(_p(grad), _p(im), _p(flow), _p(d_im), _p(d_flow), B, H, W, C)
+    return d_im, d_flow
+
+
+# --------------------------------------------------------------------------- masks / losses
+def create_mask(shape_bhw, paddings):
+    B, H, W = shape_bhw
+    (pt, pb), (pl, pr) = paddings
+    m = np.empty((B, H, W, 1), np.float32)
+    lib().oracle_create_mask(_p(m), B, H, W, pt, pb, pl, pr)
+    return m
+
+
+def create_border_mask(shape_bhw, border_ratio=0.1):
+    B, H, W = shape_bhw
+    sz = lib().oracle_border_size(H, W, border_ratio)
+    return create_mask(shape_bhw, [[sz, sz], [sz, sz]])
+
+
+def create_outgoing_mask(flow):
+    flow = _f32(flow)
+    B, H, W, _ = flow.shape
+    m = np.empty((B, H, W, 1), np.float32)
+    lib().oracle_create_outgoing_mask(_p(flow), _p(m), B, H, W)
+    return m
+
+
+def fb_occlusion(flow, flow_other_warped):
+    flow, fw = _f32(flow), _f32(flow_other_warped)
+    B, H, W, _ = flow.shape
+    diff = np.empty_like(flow)
+    occ = np.empty((B, H, W, 1), np.float32)
+    lib().oracle_fb_occlusion(_p(flow), _p(fw), _p(diff), _p(occ), B, H, W)
+    return diff, occ
+
+
+def charbonnier_loss(x, mask=None, truncate=None, alpha=0.45, beta=1.0, epsilon=0.001):
+    x = _f32(x)
+    B, H, W, C = x.shape
+    mc = 0
+    if mask is not None:
+        mask = _f32(mask)
+        mc = mask.shape[3]
+        assert mc in (1, C)
+    return lib().oracle_charbonnier_fwd(_p(x), _p(mask), mc, B, H, W, C, ctypes.c_float(alpha),
+                                        ctypes.c_float(beta), ctypes.c_float(epsilon),
+                                        ctypes.c_float(truncate if truncate else 0.0))
+
+
+def charbonnier_loss_grad(x, mask=None, gout=1.0, truncate=None, alpha=0.45, beta=1.0, epsilon=0.001):
+    x = _f32(x)
+    B, H, W, C = x.shape
+    mc = 0
+    if mask is not None:
+        mask = _f32(mask)
+        mc = mask.shape[3]
+    dx = np.empty_like(x)
+    lib().oracle_charbonnier_bwd(_p(x), _p(mask), mc, ctypes.c_float(gout), _p(dx), B, H, W, C,
+                                 ctypes.c_float(alpha), ctypes.c_float(beta), ctypes.c_float(epsilon),
+                                 ctypes.c_float(truncate if truncate else 0.0))
+    return dx
+
+
+def ternary_loss(im1, im2_warped, mask, max_distance=1, return_dist=False):
+    im1, im2_warped, mask = _f32(im1), _f32(im2_warped), _f32(mask)
+    B, H, W, C = im1.shape
+    assert C == 3
+    dist = np.empty((B, H, W, 1), np.float32) if return_dist else None
+    loss = lib().oracle_ternary_loss_fwd(_p(im1), _p(im2_warped), _p(mask), _p(dist), B, H, W,
+                                         max_distance)
+    return (loss, dist) if return_dist else loss
+
+
+def ternary_loss_grad(im1, im2_warped, mask, max_distance=1, gout=1.0):
+    im1, im2_warped, mask = _f32(im1), _f32(im2_warped), _f32(mask)
+    B, H, W, C = im1.shape
+    d = np.empty_like(im2_warped)
+    lib().oracle_ternary_loss_bwd(_p(im1), _p(im2_warped), _p(mask), ctypes.c_float(gout), _p(d), B,
+                                  H, W, max_distance)
+    return d
+
+
+# --------------------------------------------------------------------------- composite
+DISOCC_THRESH = 0.8  # losses.py:9
+
+
+def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion="",
+                   data_max_distance=1):
+    """Hot subset of losses.py:16-87: warps, masks, 'occ', 'fb', 'ternary' and
+    the disocclusion maps.  Returns (losses, aux)."""
+    im2_warped = image_warp(im2, flow_fw)
+    im1_warped = image_warp(im1, flow_bw)
+    disocc_fw = (forward_warp(flow_fw) < DISOCC_THRESH).astype(np.float32)
+    disocc_bw = (forward_warp(flow_bw) < DISOCC_THRESH).astype(np.float32)
+    if border_mask is None:
+        mask_fw = create_outgoing_mask(flow_fw)
+        mask_bw = create_outgoing_mask(flow_bw)
+    else:
+        mask_fw = _f32(border_mask).copy()
+        mask_bw = _f32(border_mask).copy()
+    flow_bw_warped = image_warp(flow_bw, flow_fw)
+    flow_fw_warped = image_warp(flow_fw, flow_bw)
+    flow_diff_fw, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped)
+    flow_diff_bw, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped)
+    if mask_occlusion == "fb":
+        mask_fw = mask_fw * (1 - fb_occ_fw)
+        mask_bw = mask_bw * (1 - fb_occ_bw)
+    elif mask_occlusion == "disocc":
+        mask_fw = mask_fw * (1 - disocc_bw)
+        mask_bw = mask_bw * (1 - disocc_fw)
+    occ_fw, occ_bw = 1 - mask_fw, 1 - mask_bw
+    losses = {
+        "sym": charbonnier_loss(occ_fw - disocc_bw) + charbonnier_loss(occ_bw - disocc_fw),
+        "occ": charbonnier_loss(occ_fw) + charbonnier_loss(occ_bw),
+        "photo": charbonnier_loss(_f32(im1) - im2_warped, mask_fw, beta=255) +
+                 charbonnier_loss(_f32(im2) - im1_warped, mask_bw, beta=255),
+        "fb": charbonnier_loss(flow_diff_fw, mask_fw) + charbonnier_loss(flow_diff_bw, mask_bw),
+        "ternary": ternary_loss(im1, im2_warped, mask_fw, data_max_distance) +
+                   ternary_loss(im2, im1_warped, mask_bw, data_max_distance),
+    }
+    aux = dict(im2_warped=im2_warped, im1_warped=im1_warped, mask_fw=mask_fw, mask_bw=mask_bw,
+               disocc_fw=disocc_fw, disocc_bw=disocc_bw, flow_bw_warped=flow_bw_warped,
+               flow_fw_warped=flow_fw_warped, flow_diff_fw=flow_diff_fw, flow_diff_bw=flow_diff_bw,
+               fb_occ_fw=fb_occ_fw, fb_occ_bw=fb_occ_bw)
+    return losses, aux

@@ -1,0 +1,157 @@
+"""The CPU oracle against every known-answer vector the reference's own tests
+hold for this path (tests/golden/reference_kat.json), against the independent
+numpy restatement, and against analytic spot values."""
+import numpy as np
+import pytest
+
+from oracle import np_ref
+
+
+def A(x):
+    return np.asarray(x, np.float32)
+
+
+@pytest.mark.parametrize("name", ["warp_move", "backward_warp_batches", "image_warp_batches",
+                                  "warp_interpolate"])
+def test_warp_known_answers(kat, oracle_mod, name):
+    case = kat[name]
+    for op in case["applies_to"]:
+        got = getattr(oracle_mod, op)(A(case["image"]), A(case["flow"]))
+        # assertAllClose defaults of tf.test.TestCase: rtol=atol=1e-6
+        np.testing.assert_allclose(got, A(case["expected"]), rtol=1e-6, atol=1e-6, err_msg=op)
+
+
+@pytest.mark.parametrize("name", ["correlation_trivial", "correlation_batch"])
+def test_correlation_known_answers(kat, oracle_mod, name):
+    case = kat[name]
+    out, p0, p1 = oracle_mod.correlation(A(case["first"]), A(case["second"]), **case["attrs"])
+    np.testing.assert_allclose(out, A(case["expected"]), rtol=1e-6, atol=1e-6)
+    assert p0.shape == (out.shape[0], 4, 4, 1)
+
+
+def test_downsample_known_answer(kat, oracle_mod):
+    case = kat["downsample"]
+    got = oracle_mod.downsample(A(case["image"]), case["scale"])
+    np.testing.assert_allclose(got, A(case["expected"]), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["outgoing_mask_all_directions", "outgoing_mask_large_movement"])
+def test_outgoing_mask_known_answers(kat, oracle_mod, name):
+    case = kat[name]
+    got = oracle_mod.create_outgoing_mask(A(case["flow"]))
+    np.testing.assert_array_equal(got[0, :, :, 0], A(case["expected"]))
+
+
+def test_correlation_geometry_flownetc(oracle_mod):
+    g = oracle_mod.correlation_geometry(48, 160)
+    assert g == dict(out_channels=441, out_height=48, out_width=160, padded_height=88, padded_width=200)
+
+
+def test_correlation_errors(oracle_mod):
+    f = np.zeros((1, 1, 4, 4), np.float32)
+    with pytest.raises(ValueError, match="kernel_size must be odd"):
+        oracle_mod.correlation(f, f, kernel_size=2)
+    with pytest.raises(ValueError, match="Input shapes have to be the same"):
+        oracle_mod.correlation(f, np.zeros((1, 1, 4, 5), np.float32))
+    with pytest.raises(ValueError, match="Invalid correlation settings"):
+        oracle_mod.correlation(f, f, max_displacement=20, pad=0)
+    with pytest.raises(ValueError, match="divisible by scale"):
+        oracle_mod.downsample(np.zeros((1, 5, 4, 1), np.float32), 2)
+
+
+def test_correlation_self_zero_displacement_is_mean_square(oracle_mod):
+    rng = np.random.default_rng(0)
+    f = rng.standard_normal((1, 8, 6, 7)).astype(np.float32)
+    out, _, _ = oracle_mod.correlation(f, f, max_displacement=4, pad=4, stride_2=2)
+    centre = out.shape[1] // 2
+    np.testing.assert_allclose(out[:, centre], (f.astype(np.float64) ** 2).mean(1), rtol=1e-6)
+
+
+@pytest.mark.parametrize("attrs", [
+    dict(),  # FlowNetC defaults
+    dict(kernel_size=3, max_displacement=1, pad=2, stride_1=1, stride_2=1),  # the disabled 3x3 test's settings
+    dict(kernel_size=3, max_displacement=4, pad=3, stride_1=2, stride_2=2),
+    dict(kernel_size=1, max_displacement=5, pad=2, stride_1=1, stride_2=2),  # pad < max_displacement
+    dict(kernel_size=5, max_displacement=3, pad=6, stride_1=3, stride_2=1),
+])
+def test_correlation_vs_closed_form(oracle_mod, attrs):
+    rng = np.random.default_rng(1)
+    f0 = rng.standard_normal((2, 6, 9, 11)).astype(np.float32)
+    f1 = rng.standard_normal((2, 6, 9, 11)).astype(np.float32)
+    out, p0, p1 = oracle_mod.correlation(f0, f1, **attrs)
+    np.testing.assert_allclose(out, np_ref.correlation(f0, f1, **attrs), rtol=1e-5, atol=1e-6)
+    top = rng.standard_normal(out.shape).astype(np.float32)
+    g0, g1 = oracle_mod.correlation_grad(top, f0, f1, p0, p1, **attrs)
+    r0, r1 = np_ref.correlation_grad(top, f0, f1, **attrs)
+    np.testing.assert_allclose(g0, r0, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(g1, r1, rtol=1e-4, atol=1e-5)
+
+
+def test_forward_warp_analytic_values(oracle_mod):
+    # zero flow: interior = (sum_{d=-4..4} exp(-d^2/2))^2, corner = (sum_{d=0..4})^2
+    out = oracle_mod.forward_warp(np.zeros((1, 12, 12, 2), np.float32))
+    s_full = sum(np.exp(-d * d / 2.0) for d in range(-4, 5))
+    s_half = sum(np.exp(-d * d / 2.0) for d in range(0, 5))
+    np.testing.assert_allclose(out[0, 6, 6, 0], s_full ** 2, rtol=1e-6)
+    np.testing.assert_allclose(out[0, 0, 0, 0], s_half ** 2, rtol=1e-6)
+    assert abs(s_full ** 2 - 6.2831479) < 1e-5 and abs(s_half ** 2 - 3.0740974) < 1e-5
+
+
+def test_forward_warp_vs_gather_form(oracle_mod):
+    rng = np.random.default_rng(2)
+    flow = (rng.standard_normal((2, 9, 11, 2)) * 4).astype(np.float32)
+    flow[0, 0, 0] = [-30, 2]     # window entirely outside
+    flow[0, 1, 1] = [-5.5, -5.2]  # window partially outside
+    np.testing.assert_allclose(oracle_mod.forward_warp(flow), np_ref.forward_warp(flow), rtol=1e-5, atol=1e-6)
+
+
+def test_image_warp_vs_backward_warp_semantics(oracle_mod):
+    """D2: clamp-to-edge vs zero-outside differ exactly where taps leave the image."""
+    im = np.ones((1, 4, 4, 1), np.float32)
+    flow = np.zeros((1, 4, 4, 2), np.float32)
+    flow[0, 0, 0] = [-2.5, 0]
+    assert oracle_mod.image_warp(im, flow)[0, 0, 0, 0] == 1.0
+    assert oracle_mod.backward_warp(im, flow)[0, 0, 0, 0] == 0.0
+
+
+def test_ternary_matches_numpy(oracle_mod):
+    rng = np.random.default_rng(3)
+    im1 = rng.uniform(size=(2, 10, 12, 3)).astype(np.float32)
+    im2 = rng.uniform(size=(2, 10, 12, 3)).astype(np.float32)
+    mask = (rng.uniform(size=(2, 10, 12, 1)) > 0.2).astype(np.float32)
+    for r in (1, 2, 3):
+        loss, dist = oracle_mod.ternary_loss(im1, im2, mask, r, return_dist=True)
+        np.testing.assert_allclose(dist[..., 0], np_ref.ternary_dist(im1, im2, r), rtol=2e-5, atol=1e-5)
+        np.testing.assert_allclose(loss, np_ref.ternary_loss(im1, im2, mask, r), rtol=1e-5)
+    # identical images: every t1 == t2, distance 0, loss = eps^(2*alpha) * mean(mask')
+    loss0 = oracle_mod.ternary_loss(im1, im1, np.ones_like(mask), 1)
+    inner = (10 - 2) * (12 - 2) / (10 * 12)
+    np.testing.assert_allclose(loss0, (0.001 ** 2) ** 0.45 * inner, rtol=1e-5)
+
+
+def test_masks(oracle_mod):
+    m = oracle_mod.create_mask((2, 5, 7), [[1, 2], [0, 3]])
+    assert m.shape == (2, 5, 7, 1)
+    assert m[0, :, :, 0].sum() == (5 - 3) * (7 - 3) and m[0, 1, 0, 0] == 1 and m[0, 0, 0, 0] == 0
+    b = oracle_mod.create_border_mask((1, 384, 1280), 0.1)  # ceil(38.4)=39
+    assert b[0, 38, 39, 0] == 0 and b[0, 39, 39, 0] == 1 and b[0, 384 - 40, 1280 - 40, 0] == 1
+
+
+def test_fb_occlusion(oracle_mod):
+    f = np.zeros((1, 2, 2, 2), np.float32)
+    w = np.zeros((1, 2, 2, 2), np.float32)
+    f[0, 0, 0] = [3, 0]
+    w[0, 0, 0] = [-3, 0]       # consistent: diff 0
+    f[0, 0, 1] = [3, 0]
+    w[0, 0, 1] = [0, 0]        # |diff|^2 = 9 > 0.01*9+0.5
+    diff, occ = oracle_mod.fb_occlusion(f, w)
+    assert occ[0, 0, 0, 0] == 0 and occ[0, 0, 1, 0] == 1 and occ[0, 1, 1, 0] == 0
+    np.testing.assert_array_equal(diff, f + w)
+
+
+def test_seeded_fixture_is_reproducible(seeded, oracle_mod):
+    """The committed oracle outputs are what the oracle computes today."""
+    c, p0, p1 = oracle_mod.correlation(seeded["corr_f0"], seeded["corr_f1"])
+    np.testing.assert_array_equal(c, seeded["corr_out"])
+    np.testing.assert_array_equal(oracle_mod.image_warp(seeded["im2"], seeded["flow"]), seeded["image_warp"])
+    np.testing.assert_allclose(oracle_mod.forward_warp(seeded["flow"]), seeded["forward_warp"], rtol=1e-6)
