@@ -1,0 +1,153 @@
+/*
+ * unflow_hip.h -- C ABI of libunflow_hip.so: UnFlow's per-pair dense hot path
+ * (FlowNetC correlation, backward/forward warping, soft ternary-census loss)
+ * as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * This is the drop-in boundary.  Each entry point replaces one launcher of the
+ * reference (paths relative to the reference checkout); a TensorFlow OpKernel,
+ * a ctypes stub or any other host binds exactly these symbols.
+ *
+ * Conventions
+ *  - All tensors are dense float32 DEVICE buffers owned by the caller, in the
+ *    reference's layouts: correlation NCHW (ops/correlation_op.cc:53-56), every
+ *    other op NHWC (ops/backward_warp_op.cu.cc:144-147).  Flow channel 0 is the
+ *    x displacement (ops/backward_warp_op.cu.cc:27-28).
+ *  - `stream` is a hipStream_t (NULL = the default stream).  Work is enqueued
+ *    asynchronously; no entry point synchronises, allocates device memory or
+ *    keeps state between calls.  The library is re-entrant.
+ *  - Return value: UNFLOW_OK, or an error code with a message retrievable
+ *    through unflow_last_error() (thread local).  UNFLOW_ERR_INVALID_ARGUMENT
+ *    messages are the reference's OP_REQUIRES strings.
+ *  - Empty tensors (any extent 0) are accepted and launch nothing
+ *    (ops/backward_warp_op.cu.cc:150).
+ */
+#ifndef UNFLOW_HIP_H_
+#define UNFLOW_HIP_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNFLOW_OK 0
+#define UNFLOW_ERR_INVALID_ARGUMENT 1 /* tf errors::InvalidArgument */
+#define UNFLOW_ERR_LAUNCH 2           /* hipGetLastError() after a launch */
+
+#define UNFLOW_ABI_VERSION 1
+
+typedef void *unflow_stream_t; /* hipStream_t */
+
+int unflow_abi_version(void);
+const char *unflow_last_error(void);
+
+/* ---------------------------------------------------------------- correlation
+ * Geometry of CorrelationState (ops/correlation_op.h:28-51).
+ * dims[5] = {out_channels, out_height, out_width, padded_height, padded_width}.
+ * Errors: "kernel_size must be odd" (ops/correlation_op.h:16-17),
+ *         "Invalid correlation settings" (ops/correlation_op.cc:60-61). */
+int unflow_correlation_geometry(int H, int W, int kernel_size, int max_displacement, int pad,
+                                int stride_1, int stride_2, int *dims);
+
+/* Replaces Correlation() (ops/correlation_op.cu.cc:250-315; op at
+ * ops/correlation_op.cc:43-85).  in0,in1 [B,C,H,W]; out [B,D,Ho,Wo].
+ * padded0/padded1 [B,H+2p,W+2p,C] are the op's outputs 1 and 2; pass NULL for
+ * both to skip materialising them (the kernels never read them). */
+int unflow_correlation_fwd(const float *in0, const float *in1, float *out, float *padded0,
+                           float *padded1, int B, int C, int H, int W, int kernel_size,
+                           int max_displacement, int pad, int stride_1, int stride_2,
+                           unflow_stream_t stream);
+
+/* Replaces CorrelationGrad() (ops/correlation_op.cu.cc:317-390; op at
+ * ops/correlation_op.cc:92-129).  topdiff [B,D,Ho,Wo]; g0,g1 [B,C,H,W].
+ * The reference reads the padded NHWC copies; this implementation reads the
+ * NCHW inputs in0,in1 directly (padded0/padded1 are accepted for signature
+ * parity and ignored; they may be NULL). */
+int unflow_correlation_bwd(const float *topdiff, const float *in0, const float *in1,
+                           const float *padded0, const float *padded1, float *g0, float *g1, int B,
+                           int C, int H, int W, int kernel_size, int max_displacement, int pad,
+                           int stride_1, int stride_2, unflow_stream_t stream);
+
+/* ---------------------------------------------------------------- backward warp
+ * Replaces BackwardWarp() / BackwardWarpGrad() (ops/backward_warp_op.cu.cc:140-190):
+ * bilinear sampling at (x+u, y+v), taps outside the image contribute zero;
+ * gradient wrt the flow only (ops.py:80-84 returns None for the image). */
+int unflow_backward_warp_fwd(const float *images, const float *flows, float *output, int B, int H,
+                             int W, int C, unflow_stream_t stream);
+int unflow_backward_warp_bwd(const float *input_grad, const float *images, const float *flows,
+                             float *output_grad, int B, int H, int W, int C, unflow_stream_t stream);
+
+/* ---------------------------------------------------------------- image_warp
+ * Replaces the TF graph of src/e2eflow/core/image_warp.py:4-76 (what the loss
+ * really calls, losses.py:22-23,38-39): floor the flow, clamp the four taps to
+ * the image.  bwd: d_im (scatter-add, zeroed by the callee) and d_flow; either
+ * may be NULL. */
+int unflow_image_warp_fwd(const float *im, const float *flow, float *warped, int B, int H, int W,
+                          int C, unflow_stream_t stream);
+int unflow_image_warp_bwd(const float *grad, const float *im, const float *flow, float *d_im,
+                          float *d_flow, int B, int H, int W, int C, unflow_stream_t stream);
+
+/* ---------------------------------------------------------------- forward warp
+ * Replaces ForwardWarp() / ForwardWarpGrad() (ops/forward_warp_op.cu.cc:127-175):
+ * Gaussian splat (sigma 1, window +-4) of unit mass; output [B,H,W,1] is zeroed
+ * by the callee.  Summation order of the atomics is not deterministic. */
+int unflow_forward_warp_fwd(const float *flows, float *output, int B, int H, int W,
+                            unflow_stream_t stream);
+int unflow_forward_warp_bwd(const float *input_grad, const float *flows, float *output_grad, int B,
+                            int H, int W, unflow_stream_t stream);
+
+/* ---------------------------------------------------------------- downsample
+ * Replaces Downsample() (ops/downsample_op.cu.cc:51-72).  Error: "Input height
+ * and width must be divisible by scale" (ops/downsample_op.cc:37-40). */
+int unflow_downsample_fwd(const float *images, float *output, int B, int H, int W, int C, int scale,
+                          unflow_stream_t stream);
+
+/* ---------------------------------------------------------------- census loss
+ * Replaces ternary_loss (src/e2eflow/core/losses.py:90-122), the soft
+ * real-valued census + "Hamming" distance + charbonnier reduction, fused.
+ *   im1, im2_warped [B,H,W,3] in [0,1]; mask [B,H,W,1].
+ *   loss:      device scalar, OVERWRITTEN with  sum / norm_count.
+ *   dldd:      optional [B,H,W] map saved for the backward pass
+ *              (mask' * d charbonnier / d dist / norm_count); may be NULL.
+ *   dist:      optional [B,H,W,1] per-pixel distance (for tests); may be NULL.
+ *   workspace: unflow_reduce_workspace_floats(B*H*W) floats.
+ *   norm_count: the charbonnier normalisation (losses.py:311-312); 0 means the
+ *              local B*H*W, a batch shard passes the GLOBAL pixel count. */
+size_t unflow_reduce_workspace_floats(long long n_pixels);
+int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped, const float *mask,
+                            float *loss, float *dldd, float *dist, float *workspace, int B, int H,
+                            int W, int max_distance, long long norm_count, unflow_stream_t stream);
+/* Gradient wrt im2_warped (im1 is stop-gradient'd upstream, core/augment.py:53).
+ * gout: device scalar upstream gradient (NULL = 1).  dldd from the forward. */
+int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped, const float *dldd,
+                            const float *gout, float *d_im2_warped, int B, int H, int W,
+                            int max_distance, unflow_stream_t stream);
+
+/* ---------------------------------------------------------------- masks, charbonnier
+ * create_outgoing_mask (losses.py:347-366): mask [B,H,W,1]. */
+int unflow_outgoing_mask(const float *flow, float *mask, int B, int H, int W, unflow_stream_t stream);
+/* create_mask (losses.py:325-335): ones inside a zero border. */
+int unflow_create_mask(float *mask, int B, int H, int W, int pad_top, int pad_bottom, int pad_left,
+                       int pad_right, unflow_stream_t stream);
+/* Forward-backward occlusion of compute_losses (losses.py:38-51):
+ * flow_diff = flow + flow_other_warped; occ = |flow_diff|^2 > 0.01*(|flow|^2 +
+ * |flow_other_warped|^2) + 0.5.  Either output may be NULL.  If mask_inout is
+ * not NULL it is multiplied by (1 - occ) (losses.py:53-55). */
+int unflow_fb_occlusion(const float *flow, const float *flow_other_warped, float *flow_diff,
+                        float *occ, float *mask_inout, int B, int H, int W, unflow_stream_t stream);
+/* charbonnier_loss (losses.py:298-322).  x [B,H,W,C]; mask NULL, [B,H,W,1]
+ * (mask_channels 1) or [B,H,W,C].  loss overwritten with sum / norm_count
+ * (0 = local B*H*W*C).  truncate <= 0 disables truncation. */
+int unflow_charbonnier_fwd(const float *x, const float *mask, int mask_channels, float *loss,
+                           float *workspace, int B, int H, int W, int C, float alpha, float beta,
+                           float epsilon, float truncate, long long norm_count,
+                           unflow_stream_t stream);
+int unflow_charbonnier_bwd(const float *x, const float *mask, int mask_channels, const float *gout,
+                           float *dx, int B, int H, int W, int C, float alpha, float beta,
+                           float epsilon, float truncate, long long norm_count,
+                           unflow_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNFLOW_HIP_H_ */

@@ -1,0 +1,321 @@
+"""Parity of the HIP path (through the C ABI of libunflow_hip.so) with the CPU
+oracle: the reference's known-answer vectors, the committed seeded fixtures and
+fresh seeded inputs.  Tolerances: 1e-5 (north_star) on warp/correlation
+tensors; census 1e-5 relative on dist_sum and the loss."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU: torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def A(x):
+    return np.asarray(x, np.float32)
+
+
+def close(got, want, rtol=1e-5, atol=1e-5, msg=""):
+    np.testing.assert_allclose(N(got) if hasattr(got, "detach") else got, want, rtol=rtol, atol=atol, err_msg=msg)
+
+
+# ----------------------------------------------------------------------------- known answers
+@pytest.mark.parametrize("name", ["warp_move", "backward_warp_batches", "image_warp_batches", "warp_interpolate"])
+def test_warp_known_answers(kat, dev, name):
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp
+    case = kat[name]
+    fns = dict(backward_warp=ops.backward_warp, image_warp=image_warp)
+    for op in case["applies_to"]:
+        got = fns[op](T(case["image"], dev), T(case["flow"], dev))
+        close(got, A(case["expected"]), 1e-6, 1e-6, op)
+
+
+@pytest.mark.parametrize("name", ["correlation_trivial", "correlation_batch"])
+def test_correlation_known_answers(kat, dev, name):
+    from unflow_amd import ops
+    case = kat[name]
+    out = ops.correlation(T(case["first"], dev), T(case["second"], dev), **case["attrs"])
+    close(out, A(case["expected"]), 1e-6, 1e-6)
+    out3 = ops.correlation_with_padded(T(case["first"], dev), T(case["second"], dev), **case["attrs"])
+    close(out3[1], np.transpose(A(case["first"]), (0, 2, 3, 1)), 0, 0)
+
+
+def test_downsample_known_answer(kat, dev):
+    from unflow_amd import ops
+    case = kat["downsample"]
+    close(ops.downsample(T(case["image"], dev), case["scale"]), A(case["expected"]), 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["outgoing_mask_all_directions", "outgoing_mask_large_movement"])
+def test_outgoing_mask_known_answers(kat, dev, name):
+    from unflow_amd import losses
+    case = kat[name]
+    got = N(losses.create_outgoing_mask(T(case["flow"], dev)))
+    np.testing.assert_array_equal(got[0, :, :, 0], A(case["expected"]))
+
+
+# ----------------------------------------------------------------------------- seeded fixtures
+def test_seeded_correlation(seeded, dev):
+    from unflow_amd import ops
+    f0, f1 = T(seeded["corr_f0"], dev), T(seeded["corr_f1"], dev)
+    close(ops.correlation(f0, f1), seeded["corr_out"])
+    g0, g1 = ops.correlation_grad(T(seeded["corr_top"], dev), f0, f1)
+    close(g0, seeded["corr_g0"])
+    close(g1, seeded["corr_g1"])
+    attrs = dict(zip(("kernel_size", "max_displacement", "pad", "stride_1", "stride_2"),
+                     [int(v) for v in seeded["corrg_attrs"]]))
+    a0, a1 = T(seeded["corrg_f0"], dev), T(seeded["corrg_f1"], dev)
+    close(ops.correlation(a0, a1, **attrs), seeded["corrg_out"])
+    h0, h1 = ops.correlation_grad(T(seeded["corrg_top"], dev), a0, a1, **attrs)
+    close(h0, seeded["corrg_g0"])
+    close(h1, seeded["corrg_g1"])
+
+
+def test_seeded_warps(seeded, dev):
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp, image_warp_grad
+    im2, flow, grad = T(seeded["im2"], dev), T(seeded["flow"], dev), T(seeded["grad"], dev)
+    close(ops.backward_warp(im2, flow), seeded["backward_warp"])
+    close(ops.backward_warp_grad(grad, im2, flow), seeded["backward_warp_grad"], 1e-5, 1e-5)
+    close(image_warp(im2, flow), seeded["image_warp"])
+    d_im, d_flow = image_warp_grad(grad, im2, flow)
+    close(d_im, seeded["image_warp_dim"], 1e-5, 1e-5)
+    close(d_flow, seeded["image_warp_dflow"], 1e-5, 1e-5)
+    close(ops.forward_warp(flow), seeded["forward_warp"], 1e-5, 1e-5)
+    close(ops.forward_warp_grad(T(seeded["forward_warp_gin"], dev), flow), seeded["forward_warp_grad"], 1e-4, 1e-5)
+    close(ops.downsample(T(seeded["im1"], dev), 2), seeded["downsample2"], 1e-6, 1e-6)
+    close(ops.downsample(T(seeded["im1"], dev), 4), seeded["downsample4"], 1e-6, 1e-6)
+
+
+@pytest.mark.parametrize("r", [1, 2, 3])
+def test_seeded_census(seeded, dev, r):
+    from unflow_amd import losses
+    im1, im2w = T(seeded["im1"], dev), T(seeded["image_warp"], dev).requires_grad_(True)
+    mask = T(seeded["border_mask"], dev)
+    assert np.abs(N(losses.ternary_dist(im1, im2w, r)) - seeded["ternary_dist_r%d" % r]).max() <= 1e-5 * (2 * r + 1) ** 2
+    loss = losses.ternary_loss(im1, im2w, mask, max_distance=r)
+    np.testing.assert_allclose(float(loss.detach()), float(seeded["ternary_loss_r%d" % r]), rtol=1e-5)
+    loss.backward()
+    want = seeded["ternary_grad_r%d" % r]
+    close(im2w.grad, want, 1e-4, 1e-4 * np.abs(want).max())  # gradients: reference checks at 1e-3
+
+
+# ----------------------------------------------------------------------------- fresh inputs vs oracle
+@pytest.mark.parametrize("shape,attrs", [
+    ((2, 32, 16, 24), dict()),                                   # FlowNetC attrs
+    ((1, 256, 16, 16), dict()),                                  # BASELINE cfg1 feature shape
+    ((1, 7, 9, 13), dict()),                                     # ragged extents and channels
+    ((2, 6, 10, 12), dict(kernel_size=3, max_displacement=4, pad=3, stride_1=2, stride_2=2)),
+    ((1, 5, 9, 11), dict(kernel_size=1, max_displacement=5, pad=2, stride_1=1, stride_2=2)),
+    ((1, 4, 12, 9), dict(kernel_size=5, max_displacement=3, pad=6, stride_1=3, stride_2=1)),
+    ((1, 8, 6, 7), dict(kernel_size=1, max_displacement=0, pad=0, stride_1=1, stride_2=1)),
+])
+def test_correlation_vs_oracle(oracle_mod, dev, shape, attrs):
+    from unflow_amd import ops
+    rng = np.random.default_rng(hash(shape) % 1000)
+    f0 = rng.standard_normal(shape).astype(np.float32)
+    f1 = rng.standard_normal(shape).astype(np.float32)
+    want, p0, p1 = oracle_mod.correlation(f0, f1, **attrs)
+    a = T(f0, dev).requires_grad_(True)
+    b = T(f1, dev).requires_grad_(True)
+    got = ops.correlation(a, b, **attrs)
+    close(got, want)
+    top = rng.standard_normal(want.shape).astype(np.float32)
+    got.backward(T(top, dev))
+    g0, g1 = oracle_mod.correlation_grad(top, f0, f1, p0, p1, **attrs)
+    close(a.grad, g0)
+    close(b.grad, g1)
+    o3 = ops.correlation_with_padded(T(f0, dev), T(f1, dev), **attrs)
+    close(o3[1], p0, 0, 0)
+    close(o3[2], p1, 0, 0)
+
+
+def test_correlation_adversarial_cancellation(oracle_mod, dev):
+    """Large-magnitude cancelling inputs: error is judged relative to sum |a*b| / C."""
+    from unflow_amd import ops
+    rng = np.random.default_rng(7)
+    f0 = (rng.standard_normal((1, 64, 8, 8)) * 1e3).astype(np.float32)
+    f1 = f0 * np.where(np.arange(64)[None, :, None, None] % 2 == 0, 1, -1).astype(np.float32)
+    want, _, _ = oracle_mod.correlation(f0, f1)
+    got = N(ops.correlation(T(f0, dev), T(f1, dev)))
+    scale = (np.abs(f0) ** 2).mean()
+    assert np.abs(got - want).max() <= 1e-5 * scale
+
+
+def test_correlation_errors(dev):
+    from unflow_amd import ops
+    f = torch.zeros((1, 1, 4, 4), device=dev)
+    with pytest.raises(ValueError, match="kernel_size must be odd"):
+        ops.correlation(f, f, kernel_size=2)
+    with pytest.raises(ValueError, match="Input shapes have to be the same"):
+        ops.correlation(f, torch.zeros((1, 1, 4, 5), device=dev))
+    with pytest.raises(ValueError, match="Invalid correlation settings"):
+        ops.correlation(f, f, max_displacement=20, pad=0)
+    with pytest.raises(ValueError, match="divisible by scale"):
+        ops.downsample(torch.zeros((1, 5, 4, 1), device=dev), 2)
+
+
+def _pair(rng, B, H, W):
+    from tests.golden.make_golden import smooth_field
+    im1 = smooth_field(rng, (B, H, W, 3), 2.0)
+    im2 = smooth_field(rng, (B, H, W, 3), 2.0)
+    flow = (rng.standard_normal((B, H, W, 2)) * 4 + rng.uniform(-10, 10, (B, 1, 1, 2))).astype(np.float32)
+    return im1, im2, flow
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 37, 53, 3), (1, 64, 96, 2), (3, 8, 8, 1), (1, 40, 33, 5)])
+def test_warps_vs_oracle(oracle_mod, dev, B, H, W, C):
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp, image_warp_grad
+    rng = np.random.default_rng(B * 1000 + H)
+    im = rng.uniform(size=(B, H, W, C)).astype(np.float32)
+    flow = (rng.standard_normal((B, H, W, 2)) * 5).astype(np.float32)
+    flow[0, 0, 0] = [-1000.0, 1000.0]   # far outside
+    flow[0, 1, 1] = [0.0, 0.0]          # exactly on the grid
+    flow[0, 2, 2] = [-1e-7, -1e-7]      # D2b: tiny negative flow
+    grad = rng.standard_normal(im.shape).astype(np.float32)
+    close(ops.backward_warp(T(im, dev), T(flow, dev)), oracle_mod.backward_warp(im, flow))
+    close(ops.backward_warp_grad(T(grad, dev), T(im, dev), T(flow, dev)), oracle_mod.backward_warp_grad(grad, im, flow))
+    close(image_warp(T(im, dev), T(flow, dev)), oracle_mod.image_warp(im, flow))
+    d_im, d_flow = image_warp_grad(T(grad, dev), T(im, dev), T(flow, dev))
+    w_im, w_flow = oracle_mod.image_warp_grad(grad, im, flow)
+    close(d_im, w_im, 1e-5, 1e-5)
+    close(d_flow, w_flow, 1e-5, 1e-5)
+
+
+def test_image_warp_autograd(oracle_mod, dev):
+    from unflow_amd.image_warp import image_warp
+    rng = np.random.default_rng(11)
+    im = rng.uniform(size=(2, 16, 20, 2)).astype(np.float32)
+    flow = (rng.standard_normal((2, 16, 20, 2)) * 3).astype(np.float32)
+    grad = rng.standard_normal(im.shape).astype(np.float32)
+    a, f = T(im, dev).requires_grad_(True), T(flow, dev).requires_grad_(True)
+    image_warp(a, f).backward(T(grad, dev))
+    w_im, w_flow = oracle_mod.image_warp_grad(grad, im, flow)
+    close(a.grad, w_im)
+    close(f.grad, w_flow)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 37, 53), (1, 10, 10), (1, 96, 128)])
+def test_forward_warp_vs_oracle(oracle_mod, dev, B, H, W):
+    from unflow_amd import ops
+    rng = np.random.default_rng(H)
+    flow = (rng.standard_normal((B, H, W, 2)) * 6).astype(np.float32)
+    flow[0, 0, 0] = [-40.0, 3.0]
+    flow[0, 1, 1] = [float(W), float(H)]
+    want = oracle_mod.forward_warp(flow)
+    f = T(flow, dev).requires_grad_(True)
+    got = ops.forward_warp(f)
+    # fp32 atomics in arbitrary order: tolerance relative to the value range (~2*pi*overlap)
+    close(got, want, 1e-5, 1e-5 * max(1.0, want.max()))
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    got.backward(T(g, dev))
+    close(f.grad, oracle_mod.forward_warp_grad(g, flow), 1e-4, 1e-5)
+
+
+def test_forward_warp_zero_flow_analytic(dev):
+    from unflow_amd import ops
+    out = N(ops.forward_warp(torch.zeros((1, 12, 12, 2), device=dev)))
+    np.testing.assert_allclose(out[0, 6, 6, 0], 6.2831479, rtol=1e-6)
+    np.testing.assert_allclose(out[0, 0, 0, 0], 3.0740974, rtol=1e-6)
+
+
+@pytest.mark.parametrize("B,H,W,r", [(2, 37, 53, 3), (1, 16, 16, 1), (2, 24, 40, 2), (1, 9, 70, 3), (1, 20, 20, 4)])
+def test_census_vs_oracle(oracle_mod, dev, B, H, W, r):
+    from unflow_amd import losses
+    rng = np.random.default_rng(B * 100 + W)
+    im1, im2, _ = _pair(rng, B, H, W)
+    mask = (rng.uniform(size=(B, H, W, 1)) > 0.15).astype(np.float32)
+    want_loss, want_dist = oracle_mod.ternary_loss(im1, im2, mask, r, return_dist=True)
+    # dist_sum lies in [0, P*P]; 1e-5 of that range.  Per-tap 1-ulp differences
+    # (v_rsq/v_rcp vs IEEE sqrt/div) are amplified by the t1-t2 cancellation on smooth images.
+    P2 = (2 * r + 1) ** 2
+    got_dist = N(losses.ternary_dist(T(im1, dev), T(im2, dev), r))
+    assert np.abs(got_dist - want_dist).max() <= 1e-5 * P2
+    assert np.abs(got_dist - want_dist).mean() <= 1e-6 * P2
+    x = T(im2, dev).requires_grad_(True)
+    loss = losses.ternary_loss(T(im1, dev), x, T(mask, dev), max_distance=r)
+    np.testing.assert_allclose(float(loss), want_loss, rtol=1e-5)
+    (loss * 2.5).backward()
+    want_grad = oracle_mod.ternary_loss_grad(im1, im2, mask, r, gout=2.5)
+    close(x.grad, want_grad, 1e-4, 1e-4 * np.abs(want_grad).max())
+
+
+def test_charbonnier_and_masks_vs_oracle(oracle_mod, dev):
+    from unflow_amd import losses
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 9, 11, 3)).astype(np.float32)
+    for mask in (None, (rng.uniform(size=(2, 9, 11, 1)) > 0.3).astype(np.float32),
+                 (rng.uniform(size=(2, 9, 11, 3)) > 0.3).astype(np.float32)):
+        for beta in (1.0, 255.0):
+            xt = T(x, dev).requires_grad_(True)
+            m = None if mask is None else T(mask, dev)
+            loss = losses.charbonnier_loss(xt, m, beta=beta)
+            np.testing.assert_allclose(float(loss), oracle_mod.charbonnier_loss(x, mask, beta=beta), rtol=1e-5)
+            loss.backward()
+            want = oracle_mod.charbonnier_loss_grad(x, mask, beta=beta)
+            close(xt.grad, want, 1e-4, 1e-6 * max(1.0, np.abs(want).max()))
+    z = torch.zeros((2, 5, 7, 1), device=dev)
+    np.testing.assert_array_equal(N(losses.create_mask(z, [[1, 2], [0, 3]])), oracle_mod.create_mask((2, 5, 7), [[1, 2], [0, 3]]))
+    big = torch.zeros((1, 384, 1280, 1), device=dev)
+    np.testing.assert_array_equal(N(losses.create_border_mask(big)), oracle_mod.create_border_mask((1, 384, 1280)))
+    f = (rng.standard_normal((2, 9, 11, 2)) * 3).astype(np.float32)
+    w = (rng.standard_normal((2, 9, 11, 2)) * 3).astype(np.float32)
+    diff, occ = losses.fb_occlusion(T(f, dev), T(w, dev))
+    wd, wo = oracle_mod.fb_occlusion(f, w)
+    close(diff, wd, 0, 0)
+    np.testing.assert_array_equal(N(occ), wo)
+
+
+@pytest.mark.parametrize("mask_occlusion,use_border", [("fb", True), ("", False), ("disocc", True)])
+def test_compute_losses_vs_oracle(oracle_mod, dev, mask_occlusion, use_border):
+    from unflow_amd import losses
+    rng = np.random.default_rng(21)
+    B, H, W = 2, 40, 56
+    im1, im2, flow_fw = _pair(rng, B, H, W)
+    flow_bw = (-flow_fw + rng.standard_normal(flow_fw.shape) * 0.5).astype(np.float32)
+    border = oracle_mod.create_border_mask((B, H, W)) if use_border else None
+    want, waux = oracle_mod.compute_losses(im1, im2, flow_fw, flow_bw, border, mask_occlusion, 3)
+    ffw, fbw = T(flow_fw, dev).requires_grad_(True), T(flow_bw, dev).requires_grad_(True)
+    got, aux = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw,
+                                     None if border is None else T(border, dev), mask_occlusion, 3,
+                                     return_aux=True)
+    for k in ("mask_fw", "mask_bw", "disocc_fw", "disocc_bw", "fb_occ_fw", "fb_occ_bw"):
+        # thresholded maps: allow a handful of pixels that sit within fp32 noise of the threshold
+        assert (N(aux[k]) != waux[k]).mean() < 1e-3, k
+    close(aux["im2_warped"], waux["im2_warped"])
+    for k in ("ternary", "occ", "fb", "photo", "sym"):
+        np.testing.assert_allclose(float(got[k]), want[k], rtol=2e-4, err_msg=k)
+    # backward to the flows through census -> image_warp
+    got["ternary"].backward()
+    gim2 = oracle_mod.ternary_loss_grad(im1, waux["im2_warped"], waux["mask_fw"], 3)
+    _, want_dfw = oracle_mod.image_warp_grad(gim2, im2, flow_fw, want_im=False)
+    gim1 = oracle_mod.ternary_loss_grad(im2, waux["im1_warped"], waux["mask_bw"], 3)
+    _, want_dbw = oracle_mod.image_warp_grad(gim1, im1, flow_bw, want_im=False)
+    close(ffw.grad, want_dfw, 1e-3, 1e-4 * np.abs(want_dfw).max())
+    close(fbw.grad, want_dbw, 1e-3, 1e-4 * np.abs(want_dbw).max())
+
+
+def test_empty_inputs(dev):
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp
+    assert ops.backward_warp(torch.zeros((0, 4, 4, 3), device=dev), torch.zeros((0, 4, 4, 2), device=dev)).shape == (0, 4, 4, 3)
+    assert image_warp(torch.zeros((2, 0, 4, 3), device=dev), torch.zeros((2, 0, 4, 2), device=dev)).shape == (2, 0, 4, 3)
+    assert ops.forward_warp(torch.zeros((0, 4, 4, 2), device=dev)).shape == (0, 4, 4, 1)
+    assert ops.correlation(torch.zeros((0, 8, 4, 4), device=dev), torch.zeros((0, 8, 4, 4), device=dev)).shape == (0, 441, 4, 4)
+    assert ops.downsample(torch.zeros((0, 4, 4, 3), device=dev), 2).shape == (0, 2, 2, 3)

@@ -1,0 +1,85 @@
+"""ctypes binding of libunflow_hip.so (the C ABI declared in include/unflow_hip.h).
+
+Mirrors what src/e2eflow/ops.py:56-63 does with tf.load_op_library, minus the
+compile-on-import: the library is built ahead of time by ``make -C
+unflow_amd/csrc`` (``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunflow_hip.so")
+
+UNFLOW_OK = 0
+UNFLOW_ERR_INVALID_ARGUMENT = 1
+UNFLOW_ERR_LAUNCH = 2
+
+_I = ctypes.c_int
+_P = ctypes.c_void_p
+_F = ctypes.c_float
+_LL = ctypes.c_longlong
+
+# symbol -> (restype, argtypes); the single source of truth for the ABI on the
+# Python side (tests check it against include/unflow_hip.h).
+SIGNATURES = {
+    "unflow_abi_version": (_I, []),
+    "unflow_last_error": (ctypes.c_char_p, []),
+    "unflow_correlation_geometry": (_I, [_I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]),
+    "unflow_correlation_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "unflow_correlation_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "unflow_backward_warp_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_backward_warp_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_image_warp_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_image_warp_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_forward_warp_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
+    "unflow_forward_warp_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "unflow_downsample_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "unflow_reduce_workspace_floats": (ctypes.c_size_t, [_LL]),
+    "unflow_ternary_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),
+    "unflow_ternary_loss_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_outgoing_mask": (_I, [_P, _P, _I, _I, _I, _P]),
+    "unflow_create_mask": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "unflow_fb_occlusion": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "unflow_charbonnier_fwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _LL, _P]),
+    "unflow_charbonnier_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _LL, _P]),
+}
+
+_lib = None
+
+
+class UnflowLibraryError(ImportError):
+    pass
+
+
+def load():
+    """Load libunflow_hip.so; raise (never fall back) if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise UnflowLibraryError(
+                "libunflow_hip.so not found at %s -- build it with `make -C unflow_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if lib.unflow_abi_version() != 1:
+            raise UnflowLibraryError("libunflow_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().unflow_last_error().decode()
+
+
+def check(rc):
+    """Map a C status to the exception the reference's OP_REQUIRES would raise
+    (tf.errors.InvalidArgumentError -> ValueError here)."""
+    if rc == UNFLOW_OK:
+        return
+    msg = last_error()
+    if rc == UNFLOW_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    raise RuntimeError("unflow_hip: " + msg)

@@ -1,0 +1,381 @@
+// Soft ternary-census loss (fused), charbonnier and the mask helpers of
+// compute_losses, for gfx950.
+//
+// Reference (paths relative to the reference checkout):
+//   ternary_loss        src/e2eflow/core/losses.py:90-122
+//   charbonnier_loss    src/e2eflow/core/losses.py:298-322
+//   create_mask         src/e2eflow/core/losses.py:325-335
+//   create_outgoing_mask src/e2eflow/core/losses.py:347-366
+//   fb occlusion        src/e2eflow/core/losses.py:38-55
+//
+// The reference materialises [B,H,W,P*P] tensors about eight times per call
+// (patches, transf, norm, diff, dist ...).  Here one workgroup stages the two
+// grayscale tiles (with an r-pixel halo) in LDS once and every lane walks its
+// (2r+1)^2 window out of LDS, so HBM traffic is the 28 B/pixel of the inputs.
+// The kernel is transcendental-rate bound: 2 v_rsq_f32 + 1 v_rcp_f32 per tap.
+#include "common.h"
+
+namespace unflow {
+namespace {
+
+constexpr int kTW = 32, kTH = 8, kNT = kTW * kTH;  // one lane per pixel of a 32x8 tile
+constexpr float kAlpha = 0.45f, kEps = 0.001f;     // charbonnier defaults used by ternary_loss
+
+// tf.image.rgb_to_grayscale * 255 (losses.py:94): separately rounded terms.
+__device__ inline float gray255(const float *px) {
+  float g = __fmul_rn(px[0], 0.2989f);
+  g = __fadd_rn(g, __fmul_rn(px[1], 0.5870f));
+  g = __fadd_rn(g, __fmul_rn(px[2], 0.1140f));
+  return __fmul_rn(g, 255.0f);
+}
+
+// Stage gray tiles of both images (zero outside the image = conv2d SAME).
+__device__ inline void stage_gray(const float *__restrict__ im1, const float *__restrict__ im2, float *g1,
+                                  float *g2, long long item_px, int H, int W, int x0, int y0, int r, int lw,
+                                  int lh) {
+  for (int i = threadIdx.x; i < lw * lh; i += kNT) {
+    const int ly = i / lw, lx = i - ly * lw;
+    const int y = y0 + ly - r, x = x0 + lx - r;
+    float a = 0.f, b = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const long long p = (item_px + (long long)y * W + x) * 3;
+      a = gray255(im1 + p);
+      b = gray255(im2 + p);
+    }
+    g1[i] = a;
+    g2[i] = b;
+  }
+}
+
+template <int R>
+__global__ __launch_bounds__(kNT) void ternary_fwd_kernel(const float *__restrict__ im1,
+                                                          const float *__restrict__ im2,
+                                                          const float *__restrict__ mask,
+                                                          float *__restrict__ partial,
+                                                          float *__restrict__ dldd, float *__restrict__ dist_out,
+                                                          int H, int W, int r_rt, float inv_norm) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int r = R > 0 ? R : r_rt;
+  const int lw = kTW + 2 * r, lh = kTH + 2 * r;
+  float *g1 = lds, *g2 = lds + lw * lh;
+  const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+  const long long item_px = (long long)blockIdx.z * H * W;
+  stage_gray(im1, im2, g1, g2, item_px, H, W, x0, y0, r, lw, lh);
+  __syncthreads();
+
+  const int tx = threadIdx.x % kTW, ty = threadIdx.x / kTW;
+  const int x = x0 + tx, y = y0 + ty;
+  float error = 0.f;
+  if (x < W && y < H) {
+    const float c1 = g1[(ty + r) * lw + tx + r], c2 = g2[(ty + r) * lw + tx + r];
+    float dist_sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * r + 1; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2 * r + 1; ++j) {
+        const float d1 = g1[(ty + i) * lw + tx + j] - c1;
+        const float d2 = g2[(ty + i) * lw + tx + j] - c2;
+        const float t1 = d1 * __builtin_amdgcn_rsqf(fmaf(d1, d1, 0.81f));
+        const float t2 = d2 * __builtin_amdgcn_rsqf(fmaf(d2, d2, 0.81f));
+        const float df = t1 - t2;
+        const float e = df * df;
+        dist_sum = fmaf(e, __builtin_amdgcn_rcpf(0.1f + e), dist_sum);
+      }
+    }
+    const long long p = item_px + (long long)y * W + x;
+    if (dist_out) dist_out[p] = dist_sum;
+    const bool inner = y >= r && y < H - r && x >= r && x < W - r;  // create_mask (losses.py:119-120)
+    const float m = inner ? mask[p] : 0.f;
+    const float base = fmaf(dist_sum, dist_sum, kEps * kEps);
+    const float pw = powf(base, kAlpha);
+    error = m * pw;
+    if (dldd) dldd[p] = m * kAlpha * (pw / base) * 2.f * dist_sum * inv_norm;
+  }
+  __shared__ float red[kNT / 64];
+  const float s = block_sum<kNT>(error, red);
+  if (threadIdx.x == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
+}
+
+// d loss / d im2_warped.  With G(d1,d2) = dh/dt2 * dt2/dd2, the gradient of the
+// gray image at q is  -sum_off (dldd[q] + dldd[q+off]) * G(I1[q+off]-I1[q], I2[q+off]-I2[q])
+// (the "q is the centre" and "q is a neighbour of q+off" terms share G up to
+// sign because the window is symmetric and t is odd in d).
+template <int R>
+__global__ __launch_bounds__(kNT) void ternary_bwd_kernel(const float *__restrict__ im1,
+                                                          const float *__restrict__ im2,
+                                                          const float *__restrict__ dldd,
+                                                          const float *__restrict__ gout,
+                                                          float *__restrict__ d_im2, int H, int W, int r_rt) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int r = R > 0 ? R : r_rt;
+  const int lw = kTW + 2 * r, lh = kTH + 2 * r;
+  float *g1 = lds, *g2 = lds + lw * lh, *gd = lds + 2 * lw * lh;
+  const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+  const long long item_px = (long long)blockIdx.z * H * W;
+  stage_gray(im1, im2, g1, g2, item_px, H, W, x0, y0, r, lw, lh);
+  for (int i = threadIdx.x; i < lw * lh; i += kNT) {
+    const int ly = i / lw, lx = i - ly * lw;
+    const int y = y0 + ly - r, x = x0 + lx - r;
+    gd[i] = (y >= 0 && y < H && x >= 0 && x < W) ? dldd[item_px + (long long)y * W + x] : 0.f;
+  }
+  __syncthreads();
+
+  const int tx = threadIdx.x % kTW, ty = threadIdx.x / kTW;
+  const int x = x0 + tx, y = y0 + ty;
+  if (x >= W || y >= H) return;
+  const int cidx = (ty + r) * lw + tx + r;
+  const float c1 = g1[cidx], c2 = g2[cidx], cd = gd[cidx];
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2 * r + 1; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2 * r + 1; ++j) {
+      const int n = (ty + i) * lw + tx + j;
+      const float w = cd + gd[n];
+      const float d1 = g1[n] - c1;
+      const float d2 = g2[n] - c2;
+      const float r1 = __builtin_amdgcn_rsqf(fmaf(d1, d1, 0.81f));
+      const float r2 = __builtin_amdgcn_rsqf(fmaf(d2, d2, 0.81f));
+      const float df = d1 * r1 - d2 * r2;
+      const float inv = __builtin_amdgcn_rcpf(fmaf(df, df, 0.1f));
+      // G = -0.2*df*inv^2 * 0.81*r2^3 ; acc -= w*G
+      acc = fmaf(w * df, (inv * inv) * (r2 * r2 * r2), acc);
+    }
+  }
+  const float go = gout ? *gout : 1.f;
+  const float dgray = acc * (0.2f * 0.81f) * go;
+  float *out = d_im2 + (item_px + (long long)y * W + x) * 3;
+  out[0] = 255.f * 0.2989f * dgray;
+  out[1] = 255.f * 0.5870f * dgray;
+  out[2] = 255.f * 0.1140f * dgray;
+}
+
+// Final pass of every loss reduction: one block, fixed order, double accumulate.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ partial, int n,
+                                                               double inv_norm, float *__restrict__ loss) {
+  __shared__ double sh[1024];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = (float)(sh[0] * inv_norm);
+}
+
+__device__ inline float charbonnier_term(float xr, float m, float alpha, float beta, float eps, float truncate) {
+  const float xv = xr * beta;
+  float e = powf(fmaf(xv, xv, eps * eps), alpha) * m;
+  if (truncate > 0.f) e = fminf(e, truncate);
+  return e;
+}
+
+__global__ __launch_bounds__(256) void charbonnier_fwd_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ mask, int mask_channels,
+                                                              float *__restrict__ partial, long long n, int C,
+                                                              float alpha, float beta, float eps, float truncate) {
+  float s = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float m = mask ? mask[mask_channels == 1 ? i / C : i] : 1.f;
+    s += charbonnier_term(x[i], m, alpha, beta, eps, truncate);
+  }
+  __shared__ float red[4];
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(256) void charbonnier_bwd_kernel(const float *__restrict__ x,
+                                                              const float *__restrict__ mask, int mask_channels,
+                                                              const float *__restrict__ gout,
+                                                              float *__restrict__ dx, long long n, int C, float alpha,
+                                                              float beta, float eps, float truncate, float inv_norm) {
+  const float go = (gout ? *gout : 1.f) * inv_norm;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float m = mask ? mask[mask_channels == 1 ? i / C : i] : 1.f;
+    const float xr = x[i];
+    const float xv = xr * beta;
+    const float base = fmaf(xv, xv, eps * eps);
+    float g = alpha * powf(base, alpha - 1.f) * 2.f * beta * beta * xr * m;
+    if (truncate > 0.f && m * powf(base, alpha) > truncate) g = 0.f;
+    dx[i] = go * g;
+  }
+}
+
+__global__ __launch_bounds__(256) void outgoing_mask_kernel(const float2 *__restrict__ flow,
+                                                            float *__restrict__ mask, int H, int W, long long n) {
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    const int gx = (int)(p % W), gy = (int)((p / W) % H);
+    const float2 f = flow[p];
+    const float pos_x = (float)gx + f.x, pos_y = (float)gy + f.y;
+    const bool inside = pos_x <= (float)(W - 1) && pos_x >= 0.f && pos_y <= (float)(H - 1) && pos_y >= 0.f;
+    mask[p] = inside ? 1.f : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void create_mask_kernel(float *__restrict__ mask, int H, int W, int pt, int pb,
+                                                          int pl, int pr, long long n) {
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    mask[p] = (y >= pt && y < H - pb && x >= pl && x < W - pr) ? 1.f : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void fb_occlusion_kernel(const float2 *__restrict__ flow,
+                                                           const float2 *__restrict__ other,
+                                                           float2 *__restrict__ flow_diff, float *__restrict__ occ,
+                                                           float *__restrict__ mask_inout, long long n) {
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    const float2 f = flow[p], w = other[p];
+    const float du = f.x + w.x, dv = f.y + w.y;
+    // length_sq = reduce_sum(square(x), 3): separately rounded squares (losses.py:12-13)
+    const float mag_sq = __fadd_rn(__fadd_rn(__fmul_rn(f.x, f.x), __fmul_rn(f.y, f.y)),
+                                   __fadd_rn(__fmul_rn(w.x, w.x), __fmul_rn(w.y, w.y)));
+    const float thresh = __fadd_rn(__fmul_rn(0.01f, mag_sq), 0.5f);
+    const float len = __fadd_rn(__fmul_rn(du, du), __fmul_rn(dv, dv));
+    const float o = len > thresh ? 1.f : 0.f;
+    if (flow_diff) flow_diff[p] = make_float2(du, dv);
+    if (occ) occ[p] = o;
+    if (mask_inout) mask_inout[p] = mask_inout[p] * (1.f - o);
+  }
+}
+
+inline unsigned ew_grid(long long n) {
+  long long g = (n + 255) / 256;
+  return (unsigned)(g < kReduceBlocks ? (g > 0 ? g : 1) : kReduceBlocks);
+}
+
+inline long long tile_blocks(int B, int H, int W) {
+  return (long long)B * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+}
+
+}  // namespace
+}  // namespace unflow
+
+using namespace unflow;
+
+extern "C" size_t unflow_reduce_workspace_floats(long long n_pixels) {
+  // >= number of 32x8 tiles of any [B,H,W] with B*H*W == n_pixels (each tile
+  // holds at least one pixel) and >= kReduceBlocks for the 1-D reductions.
+  return (size_t)(n_pixels > kReduceBlocks ? n_pixels : kReduceBlocks);
+}
+
+extern "C" int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped, const float *mask, float *loss,
+                                       float *dldd, float *dist, float *workspace, int B, int H, int W,
+                                       int max_distance, long long norm_count, unflow_stream_t stream) {
+  if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "ternary_loss: negative dimension");
+  if (max_distance < 0 || max_distance > 16)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "ternary_loss: max_distance must be in [0,16]");
+  hipStream_t s = as_stream(stream);
+  const long long npix = (long long)B * H * W;
+  if (npix == 0) {
+    // reduce_sum of an empty tensor / 0 -> NaN in TF; keep the sum (0) and do not divide.
+    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("ternary_loss memset");
+    return UNFLOW_OK;
+  }
+  const double norm = norm_count > 0 ? (double)norm_count : (double)npix;
+  const int r = max_distance;
+  const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, B);
+  const size_t smem = sizeof(float) * 2 * (kTW + 2 * r) * (kTH + 2 * r);
+  const float inv_norm = (float)(1.0 / norm);
+#define LAUNCH_FWD(R) \
+  hipLaunchKernelGGL(ternary_fwd_kernel<R>, grid, dim3(kNT), smem, s, im1, im2_warped, mask, workspace, dldd, dist, H, W, r, inv_norm)
+  switch (r) {
+    case 1: LAUNCH_FWD(1); break;
+    case 2: LAUNCH_FWD(2); break;
+    case 3: LAUNCH_FWD(3); break;
+    default: LAUNCH_FWD(0);
+  }
+#undef LAUNCH_FWD
+  if (int rc = launch_status("ternary_loss_fwd")) return rc;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, workspace, (int)tile_blocks(B, H, W),
+                     1.0 / norm, loss);
+  return launch_status("ternary_loss_fwd reduce");
+}
+
+extern "C" int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped, const float *dldd,
+                                       const float *gout, float *d_im2_warped, int B, int H, int W,
+                                       int max_distance, unflow_stream_t stream) {
+  if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "ternary_loss_grad: negative dimension");
+  if (max_distance < 0 || max_distance > 16)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "ternary_loss: max_distance must be in [0,16]");
+  if ((long long)B * H * W == 0) return UNFLOW_OK;
+  hipStream_t s = as_stream(stream);
+  const int r = max_distance;
+  const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, B);
+  const size_t smem = sizeof(float) * 3 * (kTW + 2 * r) * (kTH + 2 * r);
+#define LAUNCH_BWD(R) \
+  hipLaunchKernelGGL(ternary_bwd_kernel<R>, grid, dim3(kNT), smem, s, im1, im2_warped, dldd, gout, d_im2_warped, H, W, r)
+  switch (r) {
+    case 1: LAUNCH_BWD(1); break;
+    case 2: LAUNCH_BWD(2); break;
+    case 3: LAUNCH_BWD(3); break;
+    default: LAUNCH_BWD(0);
+  }
+#undef LAUNCH_BWD
+  return launch_status("ternary_loss_bwd");
+}
+
+extern "C" int unflow_outgoing_mask(const float *flow, float *mask, int B, int H, int W, unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (n <= 0) return n == 0 ? UNFLOW_OK : fail(UNFLOW_ERR_INVALID_ARGUMENT, "outgoing_mask: negative dimension");
+  hipLaunchKernelGGL(outgoing_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float2 *>(flow), mask, H, W, n);
+  return launch_status("outgoing_mask");
+}
+
+extern "C" int unflow_create_mask(float *mask, int B, int H, int W, int pad_top, int pad_bottom, int pad_left,
+                                  int pad_right, unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (n <= 0) return n == 0 ? UNFLOW_OK : fail(UNFLOW_ERR_INVALID_ARGUMENT, "create_mask: negative dimension");
+  hipLaunchKernelGGL(create_mask_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), mask, H, W, pad_top,
+                     pad_bottom, pad_left, pad_right, n);
+  return launch_status("create_mask");
+}
+
+extern "C" int unflow_fb_occlusion(const float *flow, const float *flow_other_warped, float *flow_diff, float *occ,
+                                   float *mask_inout, int B, int H, int W, unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (n <= 0) return n == 0 ? UNFLOW_OK : fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion: negative dimension");
+  hipLaunchKernelGGL(fb_occlusion_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other_warped),
+                     reinterpret_cast<float2 *>(flow_diff), occ, mask_inout, n);
+  return launch_status("fb_occlusion");
+}
+
+extern "C" int unflow_charbonnier_fwd(const float *x, const float *mask, int mask_channels, float *loss,
+                                      float *workspace, int B, int H, int W, int C, float alpha, float beta,
+                                      float epsilon, float truncate, long long norm_count,
+                                      unflow_stream_t stream) {
+  const long long n = (long long)B * H * W * C;
+  if (n < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "charbonnier_loss: negative dimension");
+  if (mask && mask_channels != 1 && mask_channels != C)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "charbonnier_loss: mask channels must be 1 or match x");
+  hipStream_t s = as_stream(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("charbonnier memset");
+    return UNFLOW_OK;
+  }
+  const unsigned grid = ew_grid(n);
+  hipLaunchKernelGGL(charbonnier_fwd_kernel, dim3(grid), dim3(256), 0, s, x, mask, mask_channels, workspace, n, C,
+                     alpha, beta, epsilon, truncate);
+  if (int rc = launch_status("charbonnier_fwd")) return rc;
+  const double norm = norm_count > 0 ? (double)norm_count : (double)n;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, workspace, (int)grid, 1.0 / norm, loss);
+  return launch_status("charbonnier_fwd reduce");
+}
+
+extern "C" int unflow_charbonnier_bwd(const float *x, const float *mask, int mask_channels, const float *gout,
+                                      float *dx, int B, int H, int W, int C, float alpha, float beta, float epsilon,
+                                      float truncate, long long norm_count, unflow_stream_t stream) {
+  const long long n = (long long)B * H * W * C;
+  if (n < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "charbonnier_loss_grad: negative dimension");
+  if (mask && mask_channels != 1 && mask_channels != C)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "charbonnier_loss: mask channels must be 1 or match x");
+  if (n == 0) return UNFLOW_OK;
+  const double norm = norm_count > 0 ? (double)norm_count : (double)n;
+  hipLaunchKernelGGL(charbonnier_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), x, mask,
+                     mask_channels, gout, dx, n, C, alpha, beta, epsilon, truncate, (float)(1.0 / norm));
+  return launch_status("charbonnier_bwd");
+}

@@ -1,0 +1,54 @@
+// Shared host/device helpers for libunflow_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/unflow_hip.h"
+
+namespace unflow {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// Thread-local last-error string behind unflow_last_error().
+char *error_buffer();
+int fail(int code, const char *fmt, ...);
+
+// hipGetLastError() after a launch; never synchronises.
+inline int launch_status(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(UNFLOW_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return UNFLOW_OK;
+}
+
+inline hipStream_t as_stream(unflow_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline unsigned blocks_for(long long n, int block) { return (unsigned)((n + block - 1) / block); }
+
+// Number of per-block partial sums the reductions use (fixed so the final pass
+// is one 1024-thread block and the summation order never depends on the size).
+constexpr int kReduceBlocks = 2048;
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+  return v;
+}
+
+// Sum over a block of NT threads (NT multiple of 64); result valid in thread 0.
+template <int NT>
+__device__ inline float block_sum(float v, float *lds /* NT/64 floats */) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) lds[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) r += lds[i];
+  }
+  return r;
+}
+
+}  // namespace unflow

@@ -1,0 +1,25 @@
+// Internal interface between correlation.hip (entry points, generic kernels)
+// and correlation_mfma.hip (FlowNetC-shaped fast path).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace unflow {
+
+// CorrelationState of ops/correlation_op.h:28-68 (reference checkout).
+struct CorrGeometry {
+  int H, W;
+  int pad, stride_1, stride_2, kernel_radius, max_displacement, kernel_size;
+  int grid_radius, grid_width, padded_height, padded_width, border_size;
+  int out_height, out_width, out_channels;
+};
+
+int corr_geometry_init(CorrGeometry *g, int H, int W, int kernel_size, int max_displacement, int pad,
+                       int stride_1, int stride_2);
+
+bool corr_mfma_supported(const CorrGeometry &g, int C);
+int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, const CorrGeometry &g,
+                  hipStream_t s);
+int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,
+                  const CorrGeometry &g, hipStream_t s);
+
+}  // namespace unflow

@@ -1,0 +1,443 @@
+// Warping kernels for gfx950: backward_warp (zero outside), image_warp (clamp),
+// forward_warp (Gaussian splat) and the box downsample.
+//
+// Reference semantics (paths relative to the reference checkout):
+//   backward_warp  ops/backward_warp_op.cu.cc:14-68, :70-138
+//   image_warp     src/e2eflow/core/image_warp.py:4-76
+//   forward_warp   ops/forward_warp_op.cu.cc:16-65, :67-125
+//   downsample     ops/downsample_op.cu.cc:15-49
+//
+// All four are HBM-bound gathers/scatters over NHWC images; one lane owns one
+// pixel so that the flow read (float2) and the index math are done once per
+// pixel and the channel loop is unrolled at compile time for C = 1, 2, 3.
+#include "common.h"
+
+namespace unflow {
+namespace {
+
+constexpr int kBlock = 256;
+
+struct Taps {
+  int x0, x1, y0, y1;
+  float w_left, w_right, w_top, w_bottom;
+};
+
+// BackwardWarp: floor the POSITION (ops/backward_warp_op.cu.cc:27-38).
+__device__ inline Taps position_taps(int src_x, int src_y, float2 f) {
+  Taps t;
+  const float x = (float)src_x + f.x;
+  const float y = (float)src_y + f.y;
+  t.x0 = (int)floorf(x);
+  t.x1 = t.x0 + 1;
+  t.y0 = (int)floorf(y);
+  t.y1 = t.y0 + 1;
+  t.w_right = x - (float)t.x0;
+  t.w_left = (float)t.x1 - x;
+  t.w_bottom = y - (float)t.y0;
+  t.w_top = (float)t.y1 - y;
+  return t;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void backward_warp_fwd_kernel(const float *__restrict__ images,
+                                                                   const float2 *__restrict__ flows,
+                                                                   float *__restrict__ output, int H, int W,
+                                                                   int channels, long long total) {
+  const int nc = C > 0 ? C : channels;
+  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kBlock) {
+    const int src_x = (int)(idx % W);
+    const long long row = idx / W;
+    const int src_y = (int)(row % H);
+    const long long b = row / H;
+    const Taps t = position_taps(src_x, src_y, flows[idx]);
+    const bool in_x0 = t.x0 >= 0 && t.x0 < W, in_x1 = t.x1 >= 0 && t.x1 < W;
+    const bool in_y0 = t.y0 >= 0 && t.y0 < H, in_y1 = t.y1 >= 0 && t.y1 < H;
+    const float *base = images + b * H * W * nc;
+    const float *p00 = base + ((long long)t.y0 * W + t.x0) * nc;
+    const float *p01 = p00 + nc;
+    const float *p10 = p00 + (long long)W * nc;
+    const float *p11 = p10 + nc;
+    const float w00 = t.w_left * t.w_top, w01 = t.w_right * t.w_top;
+    const float w10 = t.w_left * t.w_bottom, w11 = t.w_right * t.w_bottom;
+    float *out = output + idx * nc;
+#pragma unroll
+    for (int c = 0; c < nc; ++c) {
+      float sum = 0.f;
+      if (in_x0 && in_y0) sum = fmaf(w00, p00[c], sum);
+      if (in_x1 && in_y0) sum = fmaf(w01, p01[c], sum);
+      if (in_x0 && in_y1) sum = fmaf(w10, p10[c], sum);
+      if (in_x1 && in_y1) sum = fmaf(w11, p11[c], sum);
+      out[c] = sum;
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void backward_warp_bwd_kernel(const float *__restrict__ input_grad,
+                                                                   const float *__restrict__ images,
+                                                                   const float2 *__restrict__ flows,
+                                                                   float2 *__restrict__ output_grad, int H,
+                                                                   int W, int channels, long long total) {
+  const int nc = C > 0 ? C : channels;
+  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kBlock) {
+    const int src_x = (int)(idx % W);
+    const long long row = idx / W;
+    const int src_y = (int)(row % H);
+    const long long b = row / H;
+    const Taps t = position_taps(src_x, src_y, flows[idx]);
+    const bool in_x0 = t.x0 >= 0 && t.x0 < W, in_x1 = t.x1 >= 0 && t.x1 < W;
+    const bool in_y0 = t.y0 >= 0 && t.y0 < H, in_y1 = t.y1 >= 0 && t.y1 < H;
+    const float *base = images + b * H * W * nc;
+    const float *p00 = base + ((long long)t.y0 * W + t.x0) * nc;
+    const float *p01 = p00 + nc;
+    const float *p10 = p00 + (long long)W * nc;
+    const float *p11 = p10 + nc;
+    const float *gin = input_grad + idx * nc;
+    float du = 0.f, dv = 0.f;
+#pragma unroll
+    for (int c = 0; c < nc; ++c) {
+      const float din = gin[c];
+      if (in_x0 && in_y0) {
+        const float px = p00[c] * din;
+        du = fmaf(-t.w_top, px, du);
+        dv = fmaf(-t.w_left, px, dv);
+      }
+      if (in_x1 && in_y0) {
+        const float px = p01[c] * din;
+        du = fmaf(t.w_top, px, du);
+        dv = fmaf(-t.w_right, px, dv);
+      }
+      if (in_x0 && in_y1) {
+        const float px = p10[c] * din;
+        du = fmaf(-t.w_bottom, px, du);
+        dv = fmaf(t.w_left, px, dv);
+      }
+      if (in_x1 && in_y1) {
+        const float px = p11[c] * din;
+        du = fmaf(t.w_bottom, px, du);
+        dv = fmaf(t.w_right, px, dv);
+      }
+    }
+    output_grad[idx] = make_float2(du, dv);
+  }
+}
+
+// image_warp: floor the FLOW, clamp the taps (core/image_warp.py:26-54).
+struct ClampTaps {
+  long long ia, ib, ic, id;  // pixel indices inside the item
+  float xw, yw;
+};
+
+__device__ inline ClampTaps clamp_taps(int pos_x, int pos_y, float2 f, int H, int W) {
+  ClampTaps t;
+  const float flx = floorf(f.x), fly = floorf(f.y);
+  t.xw = f.x - flx;
+  t.yw = f.y - fly;
+  int x0 = pos_x + (int)flx, y0 = pos_y + (int)fly;
+  int x1 = x0 + 1, y1 = y0 + 1;
+  x0 = min(max(x0, 0), W - 1);
+  x1 = min(max(x1, 0), W - 1);
+  y0 = min(max(y0, 0), H - 1);
+  y1 = min(max(y1, 0), H - 1);
+  t.ia = (long long)y0 * W + x0;
+  t.ib = (long long)y1 * W + x0;
+  t.ic = (long long)y0 * W + x1;
+  t.id = (long long)y1 * W + x1;
+  return t;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void image_warp_fwd_kernel(const float *__restrict__ im,
+                                                                const float2 *__restrict__ flow,
+                                                                float *__restrict__ warped, int H, int W,
+                                                                int channels, long long total) {
+  const int nc = C > 0 ? C : channels;
+  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kBlock) {
+    const int pos_x = (int)(idx % W);
+    const long long row = idx / W;
+    const int pos_y = (int)(row % H);
+    const long long b = row / H;
+    const ClampTaps t = clamp_taps(pos_x, pos_y, flow[idx], H, W);
+    const float *base = im + b * H * W * nc;
+    const float *pa = base + t.ia * nc, *pb = base + t.ib * nc;
+    const float *pc = base + t.ic * nc, *pd = base + t.id * nc;
+    // separately rounded products combined by add_n (image_warp.py:41-44,73)
+    const float wa = (1.f - t.xw) * (1.f - t.yw);
+    const float wb = (1.f - t.xw) * t.yw;
+    const float wc = t.xw * (1.f - t.yw);
+    const float wd = t.xw * t.yw;
+    float *out = warped + idx * nc;
+#pragma unroll
+    for (int c = 0; c < nc; ++c) {
+      float s = __fmul_rn(wa, pa[c]);
+      s = __fadd_rn(s, __fmul_rn(wb, pb[c]));
+      s = __fadd_rn(s, __fmul_rn(wc, pc[c]));
+      s = __fadd_rn(s, __fmul_rn(wd, pd[c]));
+      out[c] = s;
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void image_warp_bwd_kernel(const float *__restrict__ grad,
+                                                                const float *__restrict__ im,
+                                                                const float2 *__restrict__ flow,
+                                                                float *__restrict__ d_im,
+                                                                float2 *__restrict__ d_flow, int H, int W,
+                                                                int channels, long long total) {
+  const int nc = C > 0 ? C : channels;
+  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kBlock) {
+    const int pos_x = (int)(idx % W);
+    const long long row = idx / W;
+    const int pos_y = (int)(row % H);
+    const long long b = row / H;
+    const ClampTaps t = clamp_taps(pos_x, pos_y, flow[idx], H, W);
+    const long long item = b * H * W * nc;
+    const float wa = (1.f - t.xw) * (1.f - t.yw);
+    const float wb = (1.f - t.xw) * t.yw;
+    const float wc = t.xw * (1.f - t.yw);
+    const float wd = t.xw * t.yw;
+    const float *g = grad + idx * nc;
+    float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
+#pragma unroll
+    for (int c = 0; c < nc; ++c) {
+      const float gv = g[c];
+      if (d_im) {
+        // gradient of tf.gather: scatter-add at the clamped taps
+        unsafeAtomicAdd(d_im + item + t.ia * nc + c, wa * gv);
+        unsafeAtomicAdd(d_im + item + t.ib * nc + c, wb * gv);
+        unsafeAtomicAdd(d_im + item + t.ic * nc + c, wc * gv);
+        unsafeAtomicAdd(d_im + item + t.id * nc + c, wd * gv);
+      }
+      if (d_flow) {
+        ga = fmaf(gv, im[item + t.ia * nc + c], ga);
+        gb = fmaf(gv, im[item + t.ib * nc + c], gb);
+        gc = fmaf(gv, im[item + t.ic * nc + c], gc);
+        gd = fmaf(gv, im[item + t.id * nc + c], gd);
+      }
+    }
+    if (d_flow) {
+      const float dxw = (gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw;
+      const float dyw = (gb - ga) * (1.f - t.xw) + (gd - gc) * t.xw;
+      d_flow[idx] = make_float2(dxw, dyw);
+    }
+  }
+}
+
+// ForwardWarp window (ops/forward_warp_op.cu.cc:38-51): k = ceil(dist+2) = 4.
+struct Window {
+  float tx, ty;
+  int min_x, max_x, min_y, max_y;
+  bool any;
+};
+
+__device__ inline Window splat_window(int src_x, int src_y, float2 f, int H, int W) {
+  Window w;
+  const float k = 4.f;
+  w.tx = (float)src_x + f.x;
+  w.ty = (float)src_y + f.y;
+  w.any = floorf(w.tx - k) < (float)W && floorf(w.tx + k) >= 0.f && floorf(w.ty - k) < (float)H &&
+          floorf(w.ty + k) >= 0.f;
+  w.min_x = w.tx - k > 0.f ? (int)floorf(w.tx - k) : 0;
+  w.min_y = w.ty - k > 0.f ? (int)floorf(w.ty - k) : 0;
+  w.max_x = w.tx + k < (float)W ? (int)floorf(w.tx + k) : W - 1;
+  w.max_y = w.ty + k < (float)H ? (int)floorf(w.ty + k) : H - 1;
+  return w;
+}
+
+__global__ __launch_bounds__(kBlock) void forward_warp_fwd_kernel(const float2 *__restrict__ flows,
+                                                                  float *__restrict__ output, int H, int W,
+                                                                  long long total) {
+  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kBlock) {
+    const int src_x = (int)(idx % W);
+    const long long row = idx / W;
+    const int src_y = (int)(row % H);
+    const long long b = row / H;
+    const Window w = splat_window(src_x, src_y, flows[idx], H, W);
+    if (!w.any) continue;
+    float *out = output + b * H * W;
+    // gauss_divisor = 2*std^2 = 2.  Rows outer so that neighbouring lanes
+    // (neighbouring source pixels, coherent flow) add to neighbouring addresses.
+    for (int n_y = w.min_y; n_y <= w.max_y; ++n_y) {
+      const float y = (float)n_y - w.ty;
+      const float yy = y * y;
+      for (int n_x = w.min_x; n_x <= w.max_x; ++n_x) {
+        const float x = (float)n_x - w.tx;
+        const float weight = expf(-(x * x + yy) / 2.f);
+        unsafeAtomicAdd(out + (long long)n_y * W + n_x, weight);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void forward_warp_bwd_kernel(const float *__restrict__ input_grad,
+                                                                  const float2 *__restrict__ flows,
+                                                                  float2 *__restrict__ output_grad, int H,
+                                                                  int W, long long total) {
+  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * kBlock) {
+    const int src_x = (int)(idx % W);
+    const long long row = idx / W;
+    const int src_y = (int)(row % H);
+    const long long b = row / H;
+    const Window w = splat_window(src_x, src_y, flows[idx], H, W);
+    float du = 0.f, dv = 0.f;
+    if (w.any) {
+      const float *gin = input_grad + b * H * W;
+      for (int n_x = w.min_x; n_x <= w.max_x; ++n_x) {
+        const float x = (float)n_x - w.tx;
+        const float xx = x * x;
+        for (int n_y = w.min_y; n_y <= w.max_y; ++n_y) {
+          const float y = (float)n_y - w.ty;
+          const float weight = expf(-(xx + y * y) / 2.f);
+          const float din = gin[(long long)n_y * W + n_x];
+          const float factor = 2.f * din * weight / 2.f;
+          du = fmaf(factor, x, du);
+          dv = fmaf(factor, y, dv);
+        }
+      }
+    }
+    output_grad[idx] = make_float2(du, dv);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void downsample_kernel(const float *__restrict__ images,
+                                                            float *__restrict__ output, int in_height,
+                                                            int in_width, int channels, int out_height,
+                                                            int out_width, int scale, long long total) {
+  for (long long out_idx = blockIdx.x * (long long)kBlock + threadIdx.x; out_idx < total;
+       out_idx += (long long)gridDim.x * kBlock) {
+    long long idx = out_idx;
+    const int c = (int)(idx % channels);
+    idx /= channels;
+    const int x = (int)(idx % out_width);
+    idx /= out_width;
+    const int y = (int)(idx % out_height);
+    const long long b = idx / out_height;
+    const float *src = images + ((b * in_height + (long long)y * scale) * in_width + (long long)x * scale) * channels + c;
+    float sum = 0.f;
+    for (int dy = 0; dy < scale; ++dy)
+      for (int dx = 0; dx < scale; ++dx) sum += src[((long long)dy * in_width + dx) * channels];
+    output[out_idx] = sum / (float)(scale * scale);
+  }
+}
+
+inline unsigned grid_for(long long total) {
+  // memory-bound: cap the grid and grid-stride the rest (256 CUs x 8 blocks)
+  long long g = (total + kBlock - 1) / kBlock;
+  return (unsigned)(g < 8192 ? g : 8192);
+}
+
+int check_dims(const char *op, int B, int H, int W, int C) {
+  if (B < 0 || H < 0 || W < 0 || C < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "%s: negative dimension", op);
+  return UNFLOW_OK;
+}
+
+}  // namespace
+}  // namespace unflow
+
+using namespace unflow;
+
+#define DISPATCH_C(KERNEL, C, ...)                                                               \
+  do {                                                                                           \
+    switch (C) {                                                                                 \
+      case 1: hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+      case 2: hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+      case 3: hipLaunchKernelGGL(KERNEL<3>, dim3(grid), dim3(kBlock), 0, s, __VA_ARGS__); break; \
+      default: hipLaunchKernelGGL(KERNEL<0>, dim3(grid), dim3(kBlock), 0, s, __VA_ARGS__);       \
+    }                                                                                            \
+  } while (0)
+
+extern "C" int unflow_backward_warp_fwd(const float *images, const float *flows, float *output, int B, int H,
+                                        int W, int C, unflow_stream_t stream) {
+  if (int rc = check_dims("backward_warp", B, H, W, C)) return rc;
+  const long long total = (long long)B * H * W;
+  if (total == 0 || C == 0) return UNFLOW_OK;
+  hipStream_t s = as_stream(stream);
+  const unsigned grid = grid_for(total);
+  DISPATCH_C(backward_warp_fwd_kernel, C, images, reinterpret_cast<const float2 *>(flows), output, H, W, C, total);
+  return launch_status("backward_warp_fwd");
+}
+
+extern "C" int unflow_backward_warp_bwd(const float *input_grad, const float *images, const float *flows,
+                                        float *output_grad, int B, int H, int W, int C,
+                                        unflow_stream_t stream) {
+  if (int rc = check_dims("backward_warp_grad", B, H, W, C)) return rc;
+  const long long total = (long long)B * H * W;
+  if (total == 0) return UNFLOW_OK;
+  hipStream_t s = as_stream(stream);
+  const unsigned grid = grid_for(total);
+  DISPATCH_C(backward_warp_bwd_kernel, C, input_grad, images, reinterpret_cast<const float2 *>(flows),
+             reinterpret_cast<float2 *>(output_grad), H, W, C, total);
+  return launch_status("backward_warp_bwd");
+}
+
+extern "C" int unflow_image_warp_fwd(const float *im, const float *flow, float *warped, int B, int H, int W,
+                                     int C, unflow_stream_t stream) {
+  if (int rc = check_dims("image_warp", B, H, W, C)) return rc;
+  const long long total = (long long)B * H * W;
+  if (total == 0 || C == 0) return UNFLOW_OK;
+  hipStream_t s = as_stream(stream);
+  const unsigned grid = grid_for(total);
+  DISPATCH_C(image_warp_fwd_kernel, C, im, reinterpret_cast<const float2 *>(flow), warped, H, W, C, total);
+  return launch_status("image_warp_fwd");
+}
+
+extern "C" int unflow_image_warp_bwd(const float *grad, const float *im, const float *flow, float *d_im,
+                                     float *d_flow, int B, int H, int W, int C, unflow_stream_t stream) {
+  if (int rc = check_dims("image_warp_grad", B, H, W, C)) return rc;
+  const long long total = (long long)B * H * W;
+  if (total == 0 || (!d_im && !d_flow)) return UNFLOW_OK;
+  hipStream_t s = as_stream(stream);
+  if (d_im && C > 0) {
+    if (hipMemsetAsync(d_im, 0, sizeof(float) * (size_t)total * C, s) != hipSuccess)
+      return launch_status("image_warp_bwd memset");
+  }
+  const unsigned grid = grid_for(total);
+  DISPATCH_C(image_warp_bwd_kernel, C, grad, im, reinterpret_cast<const float2 *>(flow), d_im,
+             reinterpret_cast<float2 *>(d_flow), H, W, C, total);
+  return launch_status("image_warp_bwd");
+}
+
+extern "C" int unflow_forward_warp_fwd(const float *flows, float *output, int B, int H, int W,
+                                       unflow_stream_t stream) {
+  if (int rc = check_dims("forward_warp", B, H, W, 2)) return rc;
+  const long long total = (long long)B * H * W;
+  if (total == 0) return UNFLOW_OK;
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(output, 0, sizeof(float) * (size_t)total, s) != hipSuccess)
+    return launch_status("forward_warp_fwd memset");
+  hipLaunchKernelGGL(forward_warp_fwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s,
+                     reinterpret_cast<const float2 *>(flows), output, H, W, total);
+  return launch_status("forward_warp_fwd");
+}
+
+extern "C" int unflow_forward_warp_bwd(const float *input_grad, const float *flows, float *output_grad, int B,
+                                       int H, int W, unflow_stream_t stream) {
+  if (int rc = check_dims("forward_warp_grad", B, H, W, 2)) return rc;
+  const long long total = (long long)B * H * W;
+  if (total == 0) return UNFLOW_OK;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(forward_warp_bwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, input_grad,
+                     reinterpret_cast<const float2 *>(flows), reinterpret_cast<float2 *>(output_grad), H, W,
+                     total);
+  return launch_status("forward_warp_bwd");
+}
+
+extern "C" int unflow_downsample_fwd(const float *images, float *output, int B, int H, int W, int C, int scale,
+                                     unflow_stream_t stream) {
+  if (int rc = check_dims("downsample", B, H, W, C)) return rc;
+  if (scale <= 0 || H % scale != 0 || W % scale != 0)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "Input height and width must be divisible by scale");
+  const int oh = H / scale, ow = W / scale;
+  const long long total = (long long)B * oh * ow * C;
+  if (total == 0) return UNFLOW_OK;
+  hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), images,
+                     output, H, W, C, oh, ow, scale, total);
+  return launch_status("downsample");
+}

@@ -1,0 +1,255 @@
+"""Hot subset of ``src/e2eflow/core/losses.py`` on the HIP kernels.
+
+Same function names and signatures as the reference: ``ternary_loss``
+(losses.py:90), ``charbonnier_loss`` (:298), ``create_mask`` (:325),
+``create_border_mask`` (:338), ``create_outgoing_mask`` (:347), ``length_sq``
+(:12), ``photometric_loss`` (:198) and the part of ``compute_losses`` (:16-87)
+that feeds the census term: the four ``image_warp`` calls, the forward-backward
+occlusion masks and the two ``forward_warp`` disocclusion maps.  The smoothness
+/ gradient / diffusion terms are 3x3 TF convs outside this path.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from .image_warp import image_warp
+from .ops import _check_flow, _dev, _ptr, _require_rank4, _stream, forward_warp
+
+DISOCC_THRESH = 0.8  # losses.py:9
+
+
+def _workspace(n_pixels, device):
+    n = _lib.load().unflow_reduce_workspace_floats(int(n_pixels))
+    return torch.empty(int(n), device=device, dtype=torch.float32)
+
+
+def length_sq(x):
+    return torch.sum(torch.square(x), 3, keepdim=True)
+
+
+# --------------------------------------------------------------------------- masks
+def create_mask(tensor, paddings):
+    """Ones inside, zeros on a border of paddings[0] rows / paddings[1] columns
+    (losses.py:325-335).  No gradient (tf.stop_gradient)."""
+    B, H, W = tensor.shape[0], tensor.shape[1], tensor.shape[2]
+    (pt, pb), (pl, pr) = paddings
+    mask = torch.empty((B, H, W, 1), device=tensor.device, dtype=torch.float32)
+    if not mask.is_cuda:
+        raise RuntimeError("create_mask: tensor must live on the GPU")
+    with torch.cuda.device(mask.device):
+        _lib.check(_lib.load().unflow_create_mask(_ptr(mask), B, H, W, pt, pb, pl, pr, _stream()))
+    return mask
+
+
+def border_size(height, width, border_ratio=0.1):
+    """sz of create_border_mask (losses.py:341-342), computed in float32 like TF."""
+    import numpy as np
+    return int(np.ceil(np.float32(min(height, width)) * np.float32(border_ratio)))
+
+
+def create_border_mask(tensor, border_ratio=0.1):
+    sz = border_size(tensor.shape[1], tensor.shape[2], border_ratio)
+    return create_mask(tensor, [[sz, sz], [sz, sz]])
+
+
+def create_outgoing_mask(flow):
+    """Zero where the flow carries a pixel over the image boundary (losses.py:347-366)."""
+    flow = _dev(flow.detach(), "flow")
+    _check_flow(None, flow)
+    B, H, W, _ = flow.shape
+    mask = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
+    with torch.cuda.device(flow.device):
+        _lib.check(_lib.load().unflow_outgoing_mask(_ptr(flow), _ptr(mask), B, H, W, _stream()))
+    return mask
+
+
+def fb_occlusion(flow, flow_other_warped, mask_inout=None):
+    """(flow_diff, occ) of losses.py:38-51; multiplies mask_inout by (1-occ) in place
+    when given (losses.py:53-55).  occ and the mask carry no gradient; flow_diff
+    is returned detached (use ``flow + flow_other_warped`` for a differentiable one)."""
+    flow = _dev(flow.detach(), "flow")
+    other = _dev(flow_other_warped.detach(), "flow_other_warped")
+    _check_flow(None, flow)
+    B, H, W, _ = flow.shape
+    diff = torch.empty_like(flow)
+    occ = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
+    with torch.cuda.device(flow.device):
+        _lib.check(_lib.load().unflow_fb_occlusion(_ptr(flow), _ptr(other), _ptr(diff), _ptr(occ),
+                                                   _ptr(mask_inout), B, H, W, _stream()))
+    return diff, occ
+
+
+# --------------------------------------------------------------------------- charbonnier
+class _Charbonnier(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, truncate, alpha, beta, epsilon, norm_count):
+        x = _dev(x, "x")
+        _require_rank4(x, "x")
+        B, H, W, C = x.shape
+        mc = 0
+        if mask is not None:
+            mask = _dev(mask, "mask")
+            mc = mask.shape[3]
+            if mask.shape[:3] != x.shape[:3] or mc not in (1, C):
+                raise ValueError("mask channels must be 1 or match x")
+        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        ws = _workspace(B * H * W, x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().unflow_charbonnier_fwd(
+                _ptr(x), _ptr(mask), mc, _ptr(loss), _ptr(ws), B, H, W, C, alpha, beta, epsilon,
+                truncate or 0.0, norm_count, _stream()))
+        ctx.save_for_backward(x, mask)
+        ctx.cfg = (mc, truncate or 0.0, alpha, beta, epsilon, norm_count)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, mask = ctx.saved_tensors
+        mc, truncate, alpha, beta, epsilon, norm_count = ctx.cfg
+        B, H, W, C = x.shape
+        gout = gout.contiguous()
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().unflow_charbonnier_bwd(
+                _ptr(x), _ptr(mask), mc, _ptr(gout), _ptr(dx), B, H, W, C, alpha, beta, epsilon,
+                truncate, norm_count, _stream()))
+        return dx, None, None, None, None, None, None
+
+
+def charbonnier_loss(x, mask=None, truncate=None, alpha=0.45, beta=1.0, epsilon=0.001,
+                     norm_count=0):
+    """Generalized charbonnier loss of the difference tensor x (losses.py:298-322).
+    ``norm_count`` (extension): the normalisation; 0 = batch*height*width*channels
+    of x, a batch shard passes the global element count."""
+    return _Charbonnier.apply(x, mask, truncate, alpha, beta, epsilon, norm_count)
+
+
+def photometric_loss(im_diff, mask):
+    return charbonnier_loss(im_diff, mask, beta=255)  # losses.py:198-199
+
+
+# --------------------------------------------------------------------------- census
+class _TernaryLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im1, im2_warped, mask, max_distance, norm_count):
+        im1, im2_warped = _dev(im1, "im1"), _dev(im2_warped, "im2_warped")
+        mask = _dev(mask, "mask")
+        _require_rank4(im1, "im1")
+        B, H, W, C = im1.shape
+        if C != 3 or im2_warped.shape != im1.shape:
+            raise ValueError("ternary_loss expects two [B,H,W,3] images (rgb_to_grayscale), got %s and %s"
+                             % (tuple(im1.shape), tuple(im2_warped.shape)))
+        if tuple(mask.shape) != (B, H, W, 1):
+            raise ValueError("mask must have shape %s, got %s" % ((B, H, W, 1), tuple(mask.shape)))
+        loss = torch.empty((), device=im1.device, dtype=torch.float32)
+        dldd = torch.empty((B, H, W), device=im1.device, dtype=torch.float32)
+        ws = _workspace(B * H * W, im1.device)
+        with torch.cuda.device(im1.device):
+            _lib.check(_lib.load().unflow_ternary_loss_fwd(
+                _ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss), _ptr(dldd), _ptr(None), _ptr(ws),
+                B, H, W, max_distance, norm_count, _stream()))
+        ctx.save_for_backward(im1, im2_warped, dldd)
+        ctx.max_distance = max_distance
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        im1, im2_warped, dldd = ctx.saved_tensors
+        B, H, W, _ = im1.shape
+        gout = gout.contiguous()
+        d = torch.empty_like(im2_warped)
+        with torch.cuda.device(im1.device):
+            _lib.check(_lib.load().unflow_ternary_loss_bwd(
+                _ptr(im1), _ptr(im2_warped), _ptr(dldd), _ptr(gout), _ptr(d), B, H, W,
+                ctx.max_distance, _stream()))
+        # im1 is stop-gradient'd upstream in the reference (core/augment.py:53,108)
+        return None, d, None, None, None
+
+
+def ternary_loss(im1, im2_warped, mask, max_distance=1, norm_count=0):
+    """Soft ternary census + "Hamming" distance + charbonnier (losses.py:90-122),
+    one fused kernel.  Gradient flows into ``im2_warped`` only."""
+    return _TernaryLoss.apply(im1, im2_warped, mask, max_distance, norm_count)
+
+
+def ternary_dist(im1, im2_warped, max_distance=1):
+    """Per-pixel distance map ``dist_sum`` [B,H,W,1] of losses.py:110-114 (test hook)."""
+    im1, im2_warped = _dev(im1, "im1"), _dev(im2_warped, "im2_warped")
+    B, H, W, _ = im1.shape
+    mask = torch.ones((B, H, W, 1), device=im1.device, dtype=torch.float32)
+    loss = torch.empty((), device=im1.device, dtype=torch.float32)
+    dist = torch.empty((B, H, W, 1), device=im1.device, dtype=torch.float32)
+    ws = _workspace(B * H * W, im1.device)
+    with torch.cuda.device(im1.device):
+        _lib.check(_lib.load().unflow_ternary_loss_fwd(
+            _ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss), _ptr(None), _ptr(dist), _ptr(ws), B,
+            H, W, max_distance, 0, _stream()))
+    return dist
+
+
+# --------------------------------------------------------------------------- composite
+def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion='',
+                   data_max_distance=1, norm_batch=0, with_disocc=True, return_aux=False):
+    """The census-feeding part of ``compute_losses`` (losses.py:16-87).
+
+    Returns the dict entries this path owns: 'ternary', 'occ', 'fb', 'photo'
+    (+ 'sym' when the disocclusion maps are computed).  ``norm_batch``
+    (extension) is the GLOBAL batch size when this call sees a shard of the
+    batch; 0 = the local batch.  ``return_aux`` also returns the intermediate
+    tensors (warped images, masks, occlusion maps)."""
+    assert mask_occlusion in ['fb', 'disocc', '']
+    losses = {}
+    B, H, W, _ = im1.shape
+    nb = norm_batch or B
+    npx = nb * H * W
+
+    im2_warped = image_warp(im2, flow_fw)
+    im1_warped = image_warp(im1, flow_bw)
+    im_diff_fw = im1 - im2_warped
+    im_diff_bw = im2 - im1_warped
+
+    disocc_fw = disocc_bw = None
+    if with_disocc or mask_occlusion == 'disocc':
+        # tf.cast(forward_warp(flow) < DISOCC_THRESH): no gradient through the comparison
+        disocc_fw = (forward_warp(flow_fw.detach()) < DISOCC_THRESH).float()
+        disocc_bw = (forward_warp(flow_bw.detach()) < DISOCC_THRESH).float()
+
+    if border_mask is None:
+        mask_fw = create_outgoing_mask(flow_fw)
+        mask_bw = create_outgoing_mask(flow_bw)
+    else:
+        mask_fw = border_mask.clone()
+        mask_bw = border_mask.clone()
+
+    flow_bw_warped = image_warp(flow_bw, flow_fw)
+    flow_fw_warped = image_warp(flow_fw, flow_bw)
+    flow_diff_fw = flow_fw + flow_bw_warped
+    flow_diff_bw = flow_bw + flow_fw_warped
+    _, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
+    _, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
+    if mask_occlusion == 'disocc':
+        mask_fw = mask_fw * (1 - disocc_bw)
+        mask_bw = mask_bw * (1 - disocc_fw)
+
+    occ_fw = 1 - mask_fw
+    occ_bw = 1 - mask_bw
+
+    if disocc_fw is not None:
+        losses['sym'] = (charbonnier_loss(occ_fw - disocc_bw, norm_count=npx) +
+                         charbonnier_loss(occ_bw - disocc_fw, norm_count=npx))
+    losses['occ'] = (charbonnier_loss(occ_fw, norm_count=npx) +
+                     charbonnier_loss(occ_bw, norm_count=npx))
+    losses['photo'] = (charbonnier_loss(im_diff_fw, mask_fw, beta=255, norm_count=npx * 3) +
+                       charbonnier_loss(im_diff_bw, mask_bw, beta=255, norm_count=npx * 3))
+    losses['fb'] = (charbonnier_loss(flow_diff_fw, mask_fw, norm_count=npx * 2) +
+                    charbonnier_loss(flow_diff_bw, mask_bw, norm_count=npx * 2))
+    losses['ternary'] = (ternary_loss(im1, im2_warped, mask_fw, max_distance=data_max_distance,
+                                      norm_count=npx) +
+                         ternary_loss(im2, im1_warped, mask_bw, max_distance=data_max_distance,
+                                      norm_count=npx))
+    aux = dict(im2_warped=im2_warped, im1_warped=im1_warped, mask_fw=mask_fw, mask_bw=mask_bw,
+               disocc_fw=disocc_fw, disocc_bw=disocc_bw, flow_bw_warped=flow_bw_warped,
+               flow_fw_warped=flow_fw_warped, fb_occ_fw=fb_occ_fw, fb_occ_bw=fb_occ_bw)
+    return (losses, aux) if return_aux else losses

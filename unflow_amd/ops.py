@@ -1,0 +1,236 @@
+"""Custom-op surface of the hot path -- mirror of ``src/e2eflow/ops.py``.
+
+Same names, keyword arguments, defaults, tensor layouts and error messages as
+the reference's ``ops.correlation / backward_warp / forward_warp / downsample``
+(ops.py:69-75) and their registered gradients (ops.py:80-107).  Tensors are
+float32 ``torch`` CUDA tensors used purely as device-memory containers; every
+function forwards raw pointers to the C ABI of ``libunflow_hip.so`` on torch's
+current HIP stream.  The differentiable entry points are ``torch.autograd``
+functions wired exactly like the reference's ``RegisterGradient`` table.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+OP_NAMES = ['backward_warp', 'downsample', 'correlation', 'forward_warp']  # ops.py:11
+
+
+# --------------------------------------------------------------------------- plumbing
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _dev(t, name):
+    """float32, contiguous, on the GPU -- there is no CPU kernel (the reference
+    registers DEVICE_GPU only, ops/correlation_op.cc:189-194)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA/HIP tensor: unflow_amd has no CPU kernels" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _require_rank4(t, name):
+    if t.dim() != 4:
+        raise ValueError("%s must have rank 4, got shape %s" % (name, tuple(t.shape)))
+
+
+def correlation_output_shape(in_shape, kernel_size=1, max_displacement=20, pad=20, stride_1=1,
+                             stride_2=2):
+    """CorrelationState (ops/correlation_op.h:28-51) for an NCHW input shape.
+    Host-only; raises ValueError with the reference's messages."""
+    B, C, H, W = in_shape
+    dims = (ctypes.c_int * 5)()
+    _lib.check(_lib.load().unflow_correlation_geometry(H, W, kernel_size, max_displacement, pad,
+                                                       stride_1, stride_2, dims))
+    return dict(correlation=(B, dims[0], dims[1], dims[2]), padded=(B, dims[3], dims[4], C))
+
+
+# --------------------------------------------------------------------------- raw ops
+def _correlation_raw(first, second, materialize_padded, kernel_size, max_displacement, pad,
+                     stride_1, stride_2):
+    first, second = _dev(first, "input_0"), _dev(second, "input_1")
+    _require_rank4(first, "input_0")
+    if first.shape != second.shape:
+        raise ValueError("Input shapes have to be the same")  # ops/correlation_op.cc:47-48
+    B, C, H, W = first.shape
+    shapes = correlation_output_shape(first.shape, kernel_size, max_displacement, pad, stride_1,
+                                      stride_2)
+    out = torch.empty(shapes["correlation"], device=first.device, dtype=torch.float32)
+    p0 = p1 = None
+    if materialize_padded:
+        p0 = torch.empty(shapes["padded"], device=first.device, dtype=torch.float32)
+        p1 = torch.empty(shapes["padded"], device=first.device, dtype=torch.float32)
+    with torch.cuda.device(first.device):
+        _lib.check(_lib.load().unflow_correlation_fwd(
+            _ptr(first), _ptr(second), _ptr(out), _ptr(p0), _ptr(p1), B, C, H, W, kernel_size,
+            max_displacement, pad, stride_1, stride_2, _stream()))
+    return out, p0, p1
+
+
+def correlation_grad(in_grad, original_input_0, original_input_1, padded_0=None, padded_1=None,
+                     kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
+    """``_correlation_module.correlation_grad`` (ops/correlation_op.cc:87-129).
+    padded_0/padded_1 are accepted for signature parity and not read."""
+    in_grad = _dev(in_grad, "input_grad")
+    in0, in1 = _dev(original_input_0, "original_input_0"), _dev(original_input_1, "original_input_1")
+    B, C, H, W = in0.shape
+    shapes = correlation_output_shape(in0.shape, kernel_size, max_displacement, pad, stride_1,
+                                      stride_2)
+    if tuple(in_grad.shape) != shapes["correlation"]:
+        raise ValueError("input_grad has shape %s, expected %s" %
+                         (tuple(in_grad.shape), shapes["correlation"]))
+    g0, g1 = torch.empty_like(in0), torch.empty_like(in0)
+    with torch.cuda.device(in0.device):
+        _lib.check(_lib.load().unflow_correlation_bwd(
+            _ptr(in_grad), _ptr(in0), _ptr(in1), _ptr(padded_0), _ptr(padded_1), _ptr(g0), _ptr(g1),
+            B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, _stream()))
+    return g0, g1
+
+
+def _check_flow(images, flows):
+    _require_rank4(flows, "flows")
+    if flows.shape[3] != 2:
+        raise ValueError("flows must have 2 channels, got shape %s" % (tuple(flows.shape),))
+    if images is not None:
+        _require_rank4(images, "images")
+        if images.shape[:3] != flows.shape[:3]:
+            raise ValueError("images %s and flows %s must agree in batch, height and width" %
+                             (tuple(images.shape), tuple(flows.shape)))
+
+
+def _backward_warp_raw(images, flows):
+    images, flows = _dev(images, "images"), _dev(flows, "flows")
+    _check_flow(images, flows)
+    B, H, W, C = images.shape
+    out = torch.empty_like(images)
+    with torch.cuda.device(images.device):
+        _lib.check(_lib.load().unflow_backward_warp_fwd(_ptr(images), _ptr(flows), _ptr(out), B, H,
+                                                        W, C, _stream()))
+    return out
+
+
+def backward_warp_grad(grads, original_images, original_flows):
+    """``_backward_warp_module.backward_warp_grad`` (ops/backward_warp_op.cc:54-75)."""
+    grads, images = _dev(grads, "grads"), _dev(original_images, "original_images")
+    flows = _dev(original_flows, "original_flows")
+    _check_flow(images, flows)
+    B, H, W, C = images.shape
+    out = torch.empty_like(flows)
+    with torch.cuda.device(images.device):
+        _lib.check(_lib.load().unflow_backward_warp_bwd(_ptr(grads), _ptr(images), _ptr(flows),
+                                                        _ptr(out), B, H, W, C, _stream()))
+    return out
+
+
+def _forward_warp_raw(flows):
+    flows = _dev(flows, "flows")
+    _check_flow(None, flows)
+    B, H, W, _ = flows.shape
+    out = torch.empty((B, H, W, 1), device=flows.device, dtype=torch.float32)
+    with torch.cuda.device(flows.device):
+        _lib.check(_lib.load().unflow_forward_warp_fwd(_ptr(flows), _ptr(out), B, H, W, _stream()))
+    return out
+
+
+def forward_warp_grad(grads, original_flows):
+    """``_forward_warp_module.forward_warp_grad`` (ops/forward_warp_op.cc:57-76)."""
+    grads, flows = _dev(grads, "grads"), _dev(original_flows, "original_flows")
+    _check_flow(None, flows)
+    B, H, W, _ = flows.shape
+    out = torch.empty_like(flows)
+    with torch.cuda.device(flows.device):
+        _lib.check(_lib.load().unflow_forward_warp_bwd(_ptr(grads), _ptr(flows), _ptr(out), B, H, W,
+                                                       _stream()))
+    return out
+
+
+def downsample(images, scale=2):
+    """``ops.downsample`` (ops.py:74; attr default ops/downsample_op.cc:66).
+    Not differentiable (ops.py:107): the result is detached."""
+    images = _dev(images, "images")
+    _require_rank4(images, "images")
+    B, H, W, C = images.shape
+    if scale <= 0 or H % scale != 0 or W % scale != 0:
+        raise ValueError("Input height and width must be divisible by scale")
+    out = torch.empty((B, H // scale, W // scale, C), device=images.device, dtype=torch.float32)
+    with torch.cuda.device(images.device):
+        _lib.check(_lib.load().unflow_downsample_fwd(_ptr(images), _ptr(out), B, H, W, C, scale,
+                                                     _stream()))
+    return out
+
+
+# --------------------------------------------------------------------------- gradients (ops.py:80-104)
+class _Correlation(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, first, second, kernel_size, max_displacement, pad, stride_1, stride_2):
+        out, _, _ = _correlation_raw(first, second, False, kernel_size, max_displacement, pad,
+                                     stride_1, stride_2)
+        ctx.save_for_backward(first, second)
+        ctx.attrs = (kernel_size, max_displacement, pad, stride_1, stride_2)
+        return out
+
+    @staticmethod
+    def backward(ctx, in_grad):
+        first, second = ctx.saved_tensors
+        k, md, pad, s1, s2 = ctx.attrs
+        g0, g1 = correlation_grad(in_grad, first, second, None, None, kernel_size=k,
+                                  max_displacement=md, pad=pad, stride_1=s1, stride_2=s2)
+        return g0, g1, None, None, None, None, None
+
+
+class _BackwardWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, images, flows):
+        ctx.save_for_backward(images, flows)
+        return _backward_warp_raw(images, flows)
+
+    @staticmethod
+    def backward(ctx, grad):
+        images, flows = ctx.saved_tensors
+        return None, backward_warp_grad(grad, images, flows)  # ops.py:84: [None, grad0]
+
+
+class _ForwardWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flows):
+        ctx.save_for_backward(flows)
+        return _forward_warp_raw(flows)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (flows,) = ctx.saved_tensors
+        return forward_warp_grad(grad, flows)
+
+
+# --------------------------------------------------------------------------- public surface (ops.py:69-75)
+def correlation(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
+    """``ops.correlation`` (ops.py:69-70): output 0 of the three-output op.
+    NCHW in, NCHW ``[B, D, Ho, Wo]`` out; attr defaults ops/correlation_op.cc:136-140."""
+    return _Correlation.apply(first, second, kernel_size, max_displacement, pad, stride_1, stride_2)
+
+
+def correlation_with_padded(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1,
+                            stride_2=2):
+    """All three outputs of the reference op (``_correlation_module.correlation``):
+    (correlation, padded_0, padded_1).  Not differentiable."""
+    return _correlation_raw(first, second, True, kernel_size, max_displacement, pad, stride_1,
+                            stride_2)
+
+
+def backward_warp(images, flows):
+    """``ops.backward_warp`` (ops.py:73): NHWC images, flows [B,H,W,2]; zero outside."""
+    return _BackwardWarp.apply(images, flows)
+
+
+def forward_warp(flows):
+    """``ops.forward_warp`` (ops.py:75): flows [B,H,W,2] -> density [B,H,W,1]."""
+    return _ForwardWarp.apply(flows)
