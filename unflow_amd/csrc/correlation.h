@@ -17,6 +17,7 @@ int corr_geometry_init(CorrGeometry *g, int H, int W, int kernel_size, int max_d
                        int stride_1, int stride_2);
 
 bool corr_mfma_supported(const CorrGeometry &g, int C);
+bool corr_mfma_bwd_supported(const CorrGeometry &g, int C);
 int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, const CorrGeometry &g,
                   hipStream_t s);
 int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,

@@ -240,7 +240,7 @@ extern "C" int unflow_correlation_bwd(const float *topdiff, const float *in0, co
   const long long total = (long long)B * C * H * W;
   if (total == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
-  if (corr_mfma_supported(g, C)) return corr_mfma_bwd(topdiff, in0, in1, g0, g1, B, C, g, s);
+  if (corr_mfma_bwd_supported(g, C)) return corr_mfma_bwd(topdiff, in0, in1, g0, g1, B, C, g, s);
   hipLaunchKernelGGL(corr_bwd_generic_kernel, dim3(grid_for(total)), dim3(256), 0, s, topdiff, in0, in1, g0, g1, g,
                      C, total);
   return launch_status("correlation_bwd");
