@@ -98,7 +98,8 @@ class Workload:
         self.flow_bw.grad = None
         ls = losses.compute_losses(self.im1, self.im2, self.flow_fw, self.flow_bw,
                                    border_mask=self.border, mask_occlusion="fb",
-                                   data_max_distance=3, norm_batch=self.global_batch)
+                                   data_max_distance=3, norm_batch=self.global_batch,
+                                   terms=("ternary", "sym"))
         loss = ls["ternary"]
         loss.backward()
         if world > 1:

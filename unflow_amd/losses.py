@@ -191,13 +191,17 @@ def ternary_dist(im1, im2_warped, max_distance=1):
 
 # --------------------------------------------------------------------------- composite
 def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion='',
-                   data_max_distance=1, norm_batch=0, with_disocc=True, return_aux=False):
+                   data_max_distance=1, norm_batch=0, terms=None, return_aux=False):
     """The census-feeding part of ``compute_losses`` (losses.py:16-87).
 
     Returns the dict entries this path owns: 'ternary', 'occ', 'fb', 'photo'
-    (+ 'sym' when the disocclusion maps are computed).  ``norm_batch``
-    (extension) is the GLOBAL batch size when this call sees a shard of the
-    batch; 0 = the local batch.  ``return_aux`` also returns the intermediate
+    and 'sym'.  ``terms`` (extension) restricts the dict to the named entries --
+    TF1 only executes the graph nodes a fetched loss needs, so a config with just
+    ``ternary_weight`` never runs the others; None computes all of them.  The
+    disocclusion maps (two forward_warp calls) are computed when 'sym' is asked
+    for, when ``mask_occlusion == 'disocc'`` or when ``return_aux`` is set.
+    ``norm_batch`` (extension) is the GLOBAL batch size when this call sees a
+    shard of the batch; 0 = the local batch.  ``return_aux`` also returns the intermediate
     tensors (warped images, masks, occlusion maps)."""
     assert mask_occlusion in ['fb', 'disocc', '']
     losses = {}
@@ -207,11 +211,9 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
 
     im2_warped = image_warp(im2, flow_fw)
     im1_warped = image_warp(im1, flow_bw)
-    im_diff_fw = im1 - im2_warped
-    im_diff_bw = im2 - im1_warped
-
+    want = (lambda k: True) if terms is None else (lambda k: k in terms)
     disocc_fw = disocc_bw = None
-    if with_disocc or mask_occlusion == 'disocc':
+    if want('sym') or mask_occlusion == 'disocc' or return_aux:
         # tf.cast(forward_warp(flow) < DISOCC_THRESH): no gradient through the comparison
         disocc_fw = (forward_warp(flow_fw.detach()) < DISOCC_THRESH).float()
         disocc_bw = (forward_warp(flow_bw.detach()) < DISOCC_THRESH).float()
@@ -225,8 +227,6 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
 
     flow_bw_warped = image_warp(flow_bw, flow_fw)
     flow_fw_warped = image_warp(flow_fw, flow_bw)
-    flow_diff_fw = flow_fw + flow_bw_warped
-    flow_diff_bw = flow_bw + flow_fw_warped
     _, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
     _, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
     if mask_occlusion == 'disocc':
@@ -236,19 +236,23 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     occ_fw = 1 - mask_fw
     occ_bw = 1 - mask_bw
 
-    if disocc_fw is not None:
+    if want('sym'):
         losses['sym'] = (charbonnier_loss(occ_fw - disocc_bw, norm_count=npx) +
                          charbonnier_loss(occ_bw - disocc_fw, norm_count=npx))
-    losses['occ'] = (charbonnier_loss(occ_fw, norm_count=npx) +
-                     charbonnier_loss(occ_bw, norm_count=npx))
-    losses['photo'] = (charbonnier_loss(im_diff_fw, mask_fw, beta=255, norm_count=npx * 3) +
-                       charbonnier_loss(im_diff_bw, mask_bw, beta=255, norm_count=npx * 3))
-    losses['fb'] = (charbonnier_loss(flow_diff_fw, mask_fw, norm_count=npx * 2) +
-                    charbonnier_loss(flow_diff_bw, mask_bw, norm_count=npx * 2))
-    losses['ternary'] = (ternary_loss(im1, im2_warped, mask_fw, max_distance=data_max_distance,
-                                      norm_count=npx) +
-                         ternary_loss(im2, im1_warped, mask_bw, max_distance=data_max_distance,
-                                      norm_count=npx))
+    if want('occ'):
+        losses['occ'] = (charbonnier_loss(occ_fw, norm_count=npx) +
+                         charbonnier_loss(occ_bw, norm_count=npx))
+    if want('photo'):
+        losses['photo'] = (charbonnier_loss(im1 - im2_warped, mask_fw, beta=255, norm_count=npx * 3) +
+                           charbonnier_loss(im2 - im1_warped, mask_bw, beta=255, norm_count=npx * 3))
+    if want('fb'):
+        losses['fb'] = (charbonnier_loss(flow_fw + flow_bw_warped, mask_fw, norm_count=npx * 2) +
+                        charbonnier_loss(flow_bw + flow_fw_warped, mask_bw, norm_count=npx * 2))
+    if want('ternary'):
+        losses['ternary'] = (ternary_loss(im1, im2_warped, mask_fw, max_distance=data_max_distance,
+                                          norm_count=npx) +
+                             ternary_loss(im2, im1_warped, mask_bw, max_distance=data_max_distance,
+                                          norm_count=npx))
     aux = dict(im2_warped=im2_warped, im1_warped=im1_warped, mask_fw=mask_fw, mask_bw=mask_bw,
                disocc_fw=disocc_fw, disocc_bw=disocc_bw, flow_bw_warped=flow_bw_warped,
                flow_fw_warped=flow_fw_warped, fb_occ_fw=fb_occ_fw, fb_occ_bw=fb_occ_bw)
