@@ -1,0 +1,79 @@
+"""N>1 path on CPU: world_size-2 gloo processes shard a batch, compute their
+slice of the loss with the GLOBAL normalisation and all-reduce -- the sum must
+equal the single-process loss of the whole batch.  The per-shard arithmetic
+is done by the CPU oracle here (this is a test; the product path is the GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _inputs(B, H, W):
+    rng = np.random.default_rng(42)
+    im1 = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+    im2 = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+    mask = (rng.uniform(size=(B, H, W, 1)) > 0.2).astype(np.float32)
+    return im1, im2, mask
+
+
+def _worker(rank, world, port, B, H, W, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import oracle
+    from unflow_amd import dist as udist
+    r, w = udist.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    im1, im2, mask = _inputs(B, H, W)
+    s, e = udist.shard_range(B, rank, world)
+    # per-shard census loss, normalised by the GLOBAL pixel count:
+    # loss_local(B_local*H*W) * B_local / B
+    local = oracle.ternary_loss(im1[s:e], im2[s:e], mask[s:e], 2) * (e - s) / B if e > s else 0.0
+    losses = udist.reduce_losses({"ternary": torch.tensor(local, dtype=torch.float64),
+                                  "count": torch.tensor(float(e - s), dtype=torch.float64)})
+    buf = udist.FlatGradBuffer(1000, "cpu")
+    buf.buffer += rank + 1
+    buf.all_reduce()
+    if rank == 0:
+        out.put((float(losses["ternary"]), float(losses["count"]), float(buf.buffer[0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [4, 3])   # 3: ragged split over 2 ranks
+def test_sharded_loss_equals_global(B):
+    import oracle
+    oracle.build()
+    H, W, world = 12, 16, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + B
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    im1, im2, mask = _inputs(B, H, W)
+    want = oracle.ternary_loss(im1, im2, mask, 2)
+    np.testing.assert_allclose(got[0], want, rtol=1e-6)
+    assert got[1] == B and got[2] == 3.0   # buffer: (0+1) + (1+1)
+
+
+def test_shard_range_partitions():
+    from unflow_amd.dist import shard_range
+    for B in (0, 1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(B, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)

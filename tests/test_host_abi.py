@@ -1,0 +1,103 @@
+"""CPU-side checks of the boundary: the C-ABI library loads, exports every
+symbol include/unflow_hip.h declares (no compute calls without a GPU), host-only
+entry points behave like the reference's OP_REQUIRES checks, and the product
+path refuses to run without the HIP library or on CPU tensors."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "unflow_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(unflow_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from unflow_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libunflow_hip.so does not export " + s
+    # and the Python signature table covers exactly the header
+    assert sorted(_lib.SIGNATURES) == syms
+
+
+def test_no_cuda_or_compat_symbols_in_sources():
+    csrc = os.path.join(ROOT, "unflow_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            text = open(os.path.join(csrc, fn)).read()
+            assert "__HIP_PLATFORM" not in text and "cuda_runtime" not in text and "hipify" not in text, fn
+
+
+def test_geometry_and_errors_host_only():
+    from unflow_amd import ops
+    shp = ops.correlation_output_shape((8, 256, 48, 160))
+    assert shp == {"correlation": (8, 441, 48, 160), "padded": (8, 88, 200, 256)}
+    assert ops.correlation_output_shape((1, 1, 4, 4), kernel_size=1, max_displacement=0, pad=0,
+                                        stride_2=1)["correlation"] == (1, 1, 4, 4)
+    # stride_1 = 2 : ceil((H + 2p - 2*border)/s1)
+    assert ops.correlation_output_shape((1, 3, 11, 13), 3, 4, 3, 2, 2)["correlation"] == (1, 25, 4, 5)
+    with pytest.raises(ValueError, match="kernel_size must be odd"):
+        ops.correlation_output_shape((1, 1, 4, 4), kernel_size=2)
+    with pytest.raises(ValueError, match="Invalid correlation settings"):
+        ops.correlation_output_shape((1, 1, 4, 4), max_displacement=20, pad=0)
+
+
+def test_ops_refuse_cpu_tensors():
+    from unflow_amd import losses, ops
+    from unflow_amd.image_warp import image_warp
+    im, fl = torch.zeros(1, 4, 4, 3), torch.zeros(1, 4, 4, 2)
+    for fn, args in ((ops.backward_warp, (im, fl)), (image_warp, (im, fl)), (ops.forward_warp, (fl,)),
+                     (ops.downsample, (im, 2)), (ops.correlation, (torch.zeros(1, 2, 4, 4),) * 2),
+                     (losses.ternary_loss, (im, im, torch.ones(1, 4, 4, 1)))):
+        with pytest.raises(RuntimeError, match="no CPU kernels"):
+            fn(*args)
+
+
+def test_argument_validation_before_any_launch():
+    from unflow_amd import ops
+    # validation that needs no device work happens on the host first
+    with pytest.raises(TypeError):
+        ops.backward_warp([[0.0]], torch.zeros(1, 1, 1, 2))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    """Importing works, the first use raises: never a silent fallback."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import unflow_amd._lib as L\n"
+        "L.LIB_PATH = %r\n"
+        "L._lib = None\n"
+        "try:\n"
+        "    L.load()\n"
+        "except ImportError as e:\n"
+        "    print('RAISED', e)\n" % (ROOT, str(tmp_path / "nope.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "RAISED" in out.stdout and "no CPU fallback" in out.stdout, out.stdout + out.stderr
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "unflow_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            text = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in text and "from oracle" not in text, fn
+
+
+def test_downsample_dispatcher_mirrors_reference():
+    from unflow_amd import util
+    with pytest.raises(NotImplementedError):
+        util.downsample(torch.zeros(1, 5, 4, 1), 2)     # odd extent: reference uses resize_area
+    with pytest.raises(RuntimeError, match="no CPU kernels"):
+        util.downsample(torch.zeros(1, 4, 4, 1), 2)     # even extent reaches the op
