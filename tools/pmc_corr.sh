@@ -6,9 +6,8 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
            "SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum" \
-           "GRBM_GUI_ACTIVE TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TA_BUFFER_READ_LDS_WAVEFRONTS_sum"; do
+           "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_${what}_$i -- python $R/tools/corr_only.py 32 $what 2 > $R/gpurun_out/pmc_${what}_$i.log 2>&1
+  timeout -k 5 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_${what}_$i -- python $R/tools/corr_only.py 32 $what 2 > $R/gpurun_out/pmc_${what}_$i.log 2>&1; echo "pass $i done"
 done
 cd $R && python tools/pmc_summary.py gpurun_out/pmc_${what}_*/

@@ -15,16 +15,23 @@
 // (exact f32: a k-ordered fmaf chain), M = 16 positions, N = 16 window
 // positions (a 4x4 sub-block of Q), K = 4 channels.
 //
-// Forward kernel: one workgroup = 8 waves = {cx 0,1} x 2x2 tiles of one row
-// class cy: an 8 (class rows) x 16 (full-resolution columns) output region.
-// Channels stream through LDS in chunks of 8 (register-prefetched, double
-// buffered); each wave keeps its G tile in 36 x 4 accumulator registers.  The
-// epilogue regroups G by displacement through LDS so that every global store is
-// a 64-byte row segment of one output plane.
+// Staging.  Operands reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds): one
+// wave instruction fills 1 KiB of LDS from 64 per-lane 16-byte segments, and the
+// buffer's range check returns 0 for the zero padding and for channels >= C, so
+// no data register, no ds_write and no branch is spent on staging.  The LDS
+// images keep the NCHW row order (both column classes interleaved) because only
+// whole 16-byte row segments stream at full rate (measured, profiles/
+// ubench_lds_dma.txt: 10.3 TB/s for 224-byte row segments with dwordx4 against
+// 5-6 TB/s for any 4-byte gather that de-interleaves the classes); the price is
+// a 2-way bank conflict on the fragment reads, which the LDS has room for.  A
+// DMA instruction holds the CU's texture addresser for several cycles, so the
+// DMA of stage i+1 is issued in slices between the MFMA groups of stage i.
 #include "common.h"
 #include "correlation.h"
 
+#include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 namespace unflow {
 namespace {
@@ -39,129 +46,129 @@ constexpr int WIN = TP + 2 * R; // 24: window of one tile
 constexpr int TQ = WIN / 4;     // 6 N-tiles per dimension
 constexpr int NT = TQ * TQ;     // 36 N-tiles = accumulators per wave
 constexpr int RY = 8, RX = 8;   // region of one class in a workgroup (2x2 tiles)
-constexpr int LW = RX + 2 * R;  // 28 staged window columns
+constexpr int LW = RX + 2 * R;  // 28 staged window columns per class
 constexpr int LH = RY + 2 * R;  // 28 staged window rows
-constexpr int PLANE = LW * LH;  // 784 floats per channel
-constexpr int KC = 8;           // channels per LDS stage
+constexpr int ROWF = S * LW;    // 56 floats: one staged row, full resolution (both classes)
+constexpr int RW = S * RX;      // 16 full-resolution columns of the output region
 constexpr int NTHREADS = 512;
-static_assert(WIN % 4 == 0, "window must tile by 4");
-// ds_read_b32 of a B fragment touches, per 32-lane half, 2 channels x 4 rows x
-// 4 columns: conflict free iff the row stride is 4 * odd (mod 32) and the
-// channel-plane stride is 16 (mod 32).
-static_assert(LW % 8 == 4 && PLANE % 32 == 16, "LDS image would bank-conflict");
-
-constexpr int F1_STAGE = S * KC * PLANE;     // floats per buffer (both cx classes)
-constexpr int F0_STAGE = S * KC * RY * RX;
-constexpr int STAGE = F1_STAGE + F0_STAGE;
-constexpr int SLAB_DY = 7;                    // displacement rows per epilogue slab
-constexpr int SLAB = SLAB_DY * GW * RY * (S * RX);  // floats
-static_assert(SLAB <= 2 * STAGE, "epilogue slab must fit the staging buffers");
-static_assert(GW % SLAB_DY == 0, "slabs must tile the displacement rows");
-
-// Staging is done by LDS-DMA (buffer_load_dword ... lds): one wave instruction
-// fills 64 consecutive LDS floats from 64 per-lane buffer offsets, and the
-// buffer's range check returns 0 for the zero padding and for channels >= C,
-// so no data register, no ds_write and no branch is spent on staging.
-constexpr int PIECE = 64;
-static_assert(F1_STAGE % PIECE == 0 && F0_STAGE % PIECE == 0, "stage must split into wave pieces");
-constexpr int F1_PIECES = F1_STAGE / PIECE;            // 196
-constexpr int PIECES = STAGE / PIECE;                  // 212
 constexpr int NWAVES = NTHREADS / 64;
-constexpr int PIECES_PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;  // 27
-constexpr unsigned OOB = 0x80000000u;                  // beyond any num_records (< 2 GiB)
+constexpr unsigned OOB = 0x80000000u;   // beyond any num_records (< 2 GiB): reads as 0
+static_assert(WIN % 4 == 0, "window must tile by 4");
+
+template <int N>
+using Int = std::integral_constant<int, N>;
 
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const float *base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), (short)0, (int)bytes, 0x00020000);
 }
 
-// Byte offset (relative to channel c0 of the item) of the element that LDS slot
-// `slot` of a stage holds, or OOB for the zero padding.
-__device__ inline unsigned slot_offset(int slot, int H, int W, int cy, int ys0, int xs0) {
-  int cx, c, Y, X;
-  if (slot < F1_STAGE) {
-    cx = slot / (KC * PLANE);
-    const int r = slot - cx * (KC * PLANE);
-    c = r / PLANE;
-    const int r2 = r - c * PLANE;
-    const int row = r2 / LW, xp = r2 - row * LW;
-    Y = S * (ys0 - R + row) + cy;
-    X = S * (xs0 - R + xp) + cx;
-  } else {
-    const int s0 = slot - F1_STAGE;
-    cx = s0 / (KC * RY * RX);
-    const int r = s0 - cx * (KC * RY * RX);
-    c = r / (RY * RX);
-    const int r2 = r - c * (RY * RX);
-    const int row = r2 / RX, xp = r2 - row * RX;
-    Y = S * (ys0 + row) + cy;
-    X = S * (xs0 + xp) + cx;
-  }
-  const bool in = Y >= 0 && Y < H && X >= 0 && X < W;
-  return in ? (unsigned)(((long long)c * H * W + (long long)Y * W + X) * 4) : OOB;
+// One LDS-DMA wave instruction: 64 lanes x VEC floats, LDS destination linear.
+template <int VEC>
+__device__ inline void dma(__amdgpu_buffer_rsrc_t r, float *lds_dst, unsigned voff, int soff) {
+  // (the instruction exists for 1, 2, 4, 12 and 16 bytes per lane only)
+  static_assert(VEC == 4 || VEC == 1, "LDS-DMA moves 4 or 16 bytes per lane here");
+  if constexpr (VEC == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_dst, 16, (int)voff, soff, 0, 0);
+  else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_dst, 4, (int)voff, soff, 0, 0);
 }
 
-struct Stager {
-  unsigned voff[PIECES_PER_WAVE];
+// XCD-aware block order: hardware deals consecutive block ids round-robin to the
+// 8 XCDs; remap so that each XCD walks a contiguous range of regions (one image
+// pair's windows overlap heavily and then share that XCD's L2).
+__device__ inline int xcd_remap(int b, int nblk) { return (nblk & 7) == 0 ? (b & 7) * (nblk >> 3) + (b >> 3) : b; }
+
+// ===========================================================================
+// Forward
+// ===========================================================================
+constexpr int KC = 8;                        // channels per LDS stage
+constexpr int PLANE = LH * ROWF;             // 1568 floats: [row 28][x 56] of one channel
+constexpr int F0PL = RY * RW;                // 128 floats:  [row 8][x 16]
+constexpr int F1_STAGE = KC * PLANE;         // 12544
+constexpr int F0_STAGE = KC * F0PL;          // 1024
+constexpr int STAGE = F1_STAGE + F0_STAGE;   // 13568 floats = 53 KB
+constexpr int SLAB_DY = 7;                   // displacement rows per epilogue slab
+constexpr int SLAB = SLAB_DY * GW * RY * RW; // floats
+static_assert(SLAB <= 2 * STAGE, "epilogue slab must fit the staging buffers");
+static_assert(GW % SLAB_DY == 0, "slabs must tile the displacement rows");
+// B fragment (ds_read_b32; per 32-lane half: 2 channels x 4 rows x 4 columns of
+// one class): rows land on distinct multiples of 8 (56 = 24 mod 32), columns on
+// 2*col, so the 16 positions take the 16 banks of one parity; the half's second
+// channel takes the same banks: 2-way, the best a 16-byte aligned image allows.
+static_assert(ROWF % 32 == 24, "row stride must spread the 4 rows of a fragment");
+
+template <int VEC>
+struct FwdStager {
+  static constexpr int PIECE = 64 * VEC;
+  static_assert(F1_STAGE % PIECE == 0 && F0_STAGE % PIECE == 0, "stage must split into wave pieces");
+  static constexpr int F1_PIECES = F1_STAGE / PIECE;
+  static constexpr int PIECES = STAGE / PIECE;
+  static constexpr int PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;
+
+  unsigned voff[PER_WAVE];
   int wave;
+  __amdgpu_buffer_rsrc_t r0, r1;
+
+  // byte offset (relative to channel c0 of the item) of stage float `f`, or OOB
+  static __device__ inline unsigned offset_of(int f, int H, int W, int cy, int ys0, int xs0) {
+    int c, Y, X;
+    if (f < F1_STAGE) {
+      c = f / PLANE;
+      const int r = f - c * PLANE, row = r / ROWF, x = r - row * ROWF;
+      Y = S * (ys0 - R + row) + cy;
+      X = S * (xs0 - R) + x;
+    } else {
+      const int g = f - F1_STAGE;
+      c = g / F0PL;
+      const int r = g - c * F0PL, row = r / RW, x = r - row * RW;
+      Y = S * (ys0 + row) + cy;
+      X = S * xs0 + x;
+    }
+    // VEC > 1: X and W are multiples of VEC, so a segment is inside or outside as a whole
+    const bool in = Y >= 0 && Y < H && X >= 0 && X < W;
+    return in ? (unsigned)(((long long)c * H * W + (long long)Y * W + X) * 4) : OOB;
+  }
   __device__ inline void init(int H, int W, int cy, int ys0, int xs0) {
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __builtin_assume(wave >= 0 && wave < NWAVES);
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int j = 0; j < PIECES_PER_WAVE; ++j) {
+    for (int j = 0; j < PER_WAVE; ++j) {
       const int p = wave + NWAVES * j;
-      voff[j] = p < PIECES ? slot_offset(p * PIECE + lane, H, W, cy, ys0, xs0) : OOB;
+      voff[j] = p < PIECES ? offset_of((p * 64 + lane) * VEC, H, W, cy, ys0, xs0) : OOB;
     }
   }
-  // Enqueue the DMA of channels [c0, c0+KC) into `stage`.
-  __device__ inline void issue(float *stage, const float *in0, const float *in1, long long item, int c0, int C,
-                               long long plane, int dbg = 0) const {
-    if (dbg & 12) {  // timing experiments only (results are garbage)
-      const unsigned bytes = (unsigned)((long long)(C - c0) * plane * 4);
-      const __amdgpu_buffer_rsrc_t r1 = make_rsrc(in1 + (item * C + c0) * plane, bytes);
-      const int lane = threadIdx.x & 63;
-      if (dbg & 4) {
-#pragma unroll
-        for (int j = 0; j < PIECES_PER_WAVE; ++j)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, stage + (wave + NWAVES * j) * PIECE, 4, (wave + NWAVES * j) * 256 + lane * 4, 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < (PIECES_PER_WAVE + 3) / 4; ++j)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, stage + (wave + NWAVES * j) * PIECE * 4, 16, (wave + NWAVES * j) * 1024 + lane * 16, 0, 0, 0);
-      }
-      return;
-    }
+  __device__ inline void bind(const float *in0, const float *in1, long long item, int c0, int C, long long plane) {
     const unsigned bytes = (unsigned)((long long)(C - c0) * plane * 4);
-    const __amdgpu_buffer_rsrc_t r0 = make_rsrc(in0 + (item * C + c0) * plane, bytes);
-    const __amdgpu_buffer_rsrc_t r1 = make_rsrc(in1 + (item * C + c0) * plane, bytes);
-    __builtin_assume(wave >= 0 && wave < NWAVES);
-#pragma unroll
-    for (int j = 0; j < PIECES_PER_WAVE; ++j) {
-      const int p = wave + NWAVES * j;
-      if (p < F1_PIECES) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r1, stage + p * PIECE, 4, (int)voff[j], 0, 0, 0);
-      } else if (p < PIECES) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(r0, stage + p * PIECE, 4, (int)voff[j], 0, 0, 0);
-      }
+    r0 = make_rsrc(in0 + (item * C + c0) * plane, bytes);
+    r1 = make_rsrc(in1 + (item * C + c0) * plane, bytes);
+  }
+  template <int J>
+  __device__ inline void issue_one(float *stage) const {
+    if constexpr (J < PER_WAVE) {
+      __builtin_assume(wave >= 0 && wave < NWAVES);
+      const int p = wave + NWAVES * J;
+      if (p < F1_PIECES) dma<VEC>(r1, stage + p * PIECE, voff[J], 0);
+      else if (p < PIECES) dma<VEC>(r0, stage + p * PIECE, voff[J], 0);
+    }
+  }
+  template <int J0, int N>
+  __device__ inline void issue_range(float *stage) const {
+    if constexpr (N > 0) {
+      issue_one<J0>(stage);
+      issue_range<J0 + 1, N - 1>(stage);
     }
   }
 };
 
+template <int VEC>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float *__restrict__ in0,
                                                                     const float *__restrict__ in1,
-                                                                    float *__restrict__ out, int C, int H, int W, int nbx, int nby, int dbg) {
+                                                                    float *__restrict__ out, int C, int H, int W,
+                                                                    int nbx, int nby) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cx = wave & 1, ty = (wave >> 1) & 1, tx = wave >> 2;
-  // XCD-aware block order: hardware deals consecutive block ids round-robin to
-  // the 8 XCDs; remap so that each XCD walks a contiguous range of regions (one
-  // image pair's windows overlap heavily and then share that XCD's L2).
-  const int nblk = gridDim.x;
-  int vb = blockIdx.x;
-  if ((nblk & 7) == 0) vb = (vb & 7) * (nblk >> 3) + (vb >> 3);
-  const int bx = vb % nbx;
-  const int by = (vb / nbx) % nby;
-  const int bz = vb / (nbx * nby);
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = vb % nbx, by = (vb / nbx) % nby, bz = vb / (nbx * nby);
   const int cy = bz & 1;
   const long long item = bz >> 1;
   const int ys0 = by * RY;                   // class-row origin of the region
@@ -175,32 +182,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
 
   // per-lane fragment addresses inside one stage (floats)
   const int k = lane >> 4, n = lane & 15;
-  const int a_off = F1_STAGE + (cx * KC + k) * (RY * RX) + (ty * TP + (n >> 2)) * RX + tx * TP + (n & 3);
-  const int b_off = (cx * KC + k) * PLANE + (ty * TP + (n >> 2)) * LW + tx * TP + (n & 3);
+  const int a_off = F1_STAGE + k * F0PL + (ty * TP + (n >> 2)) * RW + S * (tx * TP + (n & 3)) + cx;
+  const int b_off = k * PLANE + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + cx;
 
-  Stager st;
+  using St = FwdStager<VEC>;
+  St st;
   st.init(H, W, cy, ys0, xs0);
   const long long plane = (long long)H * W;
   const int nchunks = (C + KC - 1) / KC;
-  st.issue(lds, in0, in1, item, 0, C, plane);
+  st.bind(in0, in1, item, 0, C, plane);
+  st.template issue_range<0, St::PER_WAVE>(lds);
   __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the stage
 
+  constexpr int GROUPS = (KC / 4) * TQ;                              // MFMA groups per chunk (12)
+  constexpr int PER_GROUP = (St::PER_WAVE + GROUPS - 1) / GROUPS;    // DMA pieces issued after each group
   for (int ch = 0; ch < nchunks; ++ch) {
     const float *cur = lds + (ch & 1) * STAGE;
-    if (ch + 1 < nchunks && !(dbg & 1)) st.issue(lds + ((ch + 1) & 1) * STAGE, in0, in1, item, (ch + 1) * KC, C, plane, dbg);
-    if (!(dbg & 2))
+    float *nxt = lds + ((ch + 1) & 1) * STAGE;
+    const bool more = ch + 1 < nchunks;
+    if (more) st.bind(in0, in1, item, (ch + 1) * KC, C, plane);
 #pragma unroll
     for (int kk = 0; kk < KC / 4; ++kk) {
       // all fragment reads of the K-step are issued first; the MFMAs then wait
       // with a decreasing lgkmcnt, so one LDS latency is exposed per 36 MFMAs
-      const float a = cur[a_off + kk * 4 * (RY * RX)];
+      const float a = cur[a_off + kk * 4 * F0PL];
       const float *bp = cur + b_off + kk * 4 * PLANE;
       float b[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = bp[(t / TQ) * 4 * LW + (t % TQ) * 4];
+      for (int t = 0; t < NT; ++t) b[t] = bp[(t / TQ) * 4 * ROWF + (t % TQ) * 4 * S];
       __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs
+      auto group = [&](auto G) {
+        constexpr int g = decltype(G)::value;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+        for (int t = g * TQ; t < (g + 1) * TQ; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+        if (more) {
+          if (kk == 0) st.template issue_range<g * PER_GROUP, PER_GROUP>(nxt);
+          else st.template issue_range<(TQ + g) * PER_GROUP, PER_GROUP>(nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      group(Int<0>{}); group(Int<1>{}); group(Int<2>{}); group(Int<3>{}); group(Int<4>{}); group(Int<5>{});
     }
     __syncthreads();
   }
@@ -216,9 +238,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   const int py = lane >> 4;
   const int row = ty * TP + py;                       // class row inside the region
   const int D = GW * GW;
-  const long long oplane = (long long)H * W;
   float *ob = lds;
-  constexpr int RW = S * RX;                          // 16 full-resolution columns
 #pragma unroll
   for (int s = 0; s < GW / SLAB_DY; ++s) {
 #pragma unroll
@@ -251,7 +271,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
       if (y >= H || x >= W) continue;
       const float *src = ob + (r * RW + c4 * 4) * (SLAB_DY * GW) + ddl * GW + dxx;
       const float4 v = make_float4(src[0], src[SLAB_DY * GW], src[2 * SLAB_DY * GW], src[3 * SLAB_DY * GW]);
-      float *dst = out + (item * D + d) * oplane + (long long)y * W + x;
+      float *dst = out + (item * D + d) * plane + (long long)y * W + x;
       if (x + 3 < W && (W & 3) == 0) {
         *reinterpret_cast<float4 *>(dst) = v;
       } else {
@@ -265,8 +285,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   }
 }
 
-
-// ---------------------------------------------------------------------------
+// ===========================================================================
 // Backward.  Both gradients are the same GEMM with the roles swapped:
 //   g0[c, o] = 1/C * sum_{w in window(o)} top[d = w - o, o] * f1[c, w]
 //   g1[c, o] = 1/C * sum_{w in window(o)} top[d = o - w, w] * f0[c, w]
@@ -277,39 +296,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
 // A = the other input's window (from LDS) and B = top gathered by displacement.
 // One workgroup = 8 waves = {cx} x 2x2 tiles (as in the forward kernel) and all
 // channels (16 M-tiles of 16, 64 accumulator registers per wave); the K loop
-// walks the 28 window rows, one row (28 columns x 256 channels x 2 classes, plus
-// the 8 x 21 top segments that pair with it) per LDS stage, filled by LDS-DMA.
+// walks the 28 window rows, one row (56 floats x 256 channels, plus the 8 x 21
+// top segments that pair with it) per LDS stage.
+// ===========================================================================
 constexpr int MT = 16;                         // M-tiles (of 16 channels) per pass
 constexpr int CW = MT * 16;                    // 256 channels per pass
-constexpr int ACS = 30;                        // A row stride: c*30 + k is conflict-free (30 = 2*odd)
-static_assert(ACS >= LW && (ACS % 4) == 2 && ((ACS / 2) & 1), "A image would bank-conflict");
-constexpr int A_STAGE = S * CW * ACS;          // 15360 floats
-constexpr int T_STAGE = RY * GW * (S * RX);    // 2688 floats: [row 8][dx 21][16 columns]
-constexpr int BW_STAGE = A_STAGE + T_STAGE;    // 18048 floats = 72 KB
-static_assert(A_STAGE % PIECE == 0 && T_STAGE % PIECE == 0, "stage must split into wave pieces");
-constexpr int A_PIECES = A_STAGE / PIECE;      // 240
-constexpr int T_PIECES = T_STAGE / PIECE;      // 42
-constexpr int A_PER_WAVE = A_PIECES / NWAVES;  // 30
-constexpr int T_PER_WAVE = (T_PIECES + NWAVES - 1) / NWAVES;  // 6
-static_assert(A_PIECES % NWAVES == 0, "A pieces must split evenly");
-constexpr int OUT_HALF = (CW / 2) * RY * (S * RX);  // epilogue image of 128 channels
+constexpr int ACS = ROWF + 4;                  // 60: channel stride of the A image (4 pad floats)
+// A fragment (16 channels x 2 window columns per half): c*60 mod 32 walks the 8
+// multiples of 4 twice, +2k takes the other even banks: 2-way (see forward note).
+static_assert(ACS % 8 == 4, "A image channel stride must be 4*odd");
+constexpr int A_STAGE = CW * ACS;              // 15360 floats
+constexpr int T_IMAGE = RY * GW * RW;          // 2688 floats: [row 8][dx' 21][16 columns]
+constexpr int T_STAGE = (T_IMAGE + 255) / 256 * 256;  // 2816: padded to whole 1-KiB DMA pieces
+constexpr int BW_STAGE = A_STAGE + T_STAGE;    // 18176 floats = 71 KB
+constexpr int OUT_HALF = (CW / 2) * RY * RW;   // epilogue image of 128 channels
 static_assert(OUT_HALF <= 2 * BW_STAGE, "epilogue image must fit the staging buffers");
+constexpr int KSTEPS = WIN / 4;                // 6 K-steps per window row and tile
 
+template <int VA, int VT>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float *__restrict__ topdiff,
                                                                     const float *__restrict__ in0,
                                                                     const float *__restrict__ in1,
                                                                     float *__restrict__ g0, float *__restrict__ g1,
                                                                     int C, int H, int W, int nbx, int nby) {
+  // VT: DMA width of the top segments of the gradient wrt input 0 (whole, aligned
+  // 64-byte segments).  For the gradient wrt input 1 the segments are shifted by
+  // the displacement (8-byte aligned only), so they always move as dwords.
+  constexpr int A_PIECE = 64 * VA;
+  static_assert(A_STAGE % A_PIECE == 0 && T_STAGE % (64 * VT) == 0, "stage must split into wave pieces");
+  constexpr int A_PIECES = A_STAGE / A_PIECE;
+  constexpr int A_PER_WAVE = (A_PIECES + NWAVES - 1) / NWAVES;
+  constexpr int APS = (A_PER_WAVE + KSTEPS - 1) / KSTEPS;   // A pieces issued per K-step
+  static_assert((T_STAGE / 64 + NWAVES - 1) / NWAVES <= KSTEPS, "one top piece per K-step must cover the stage");
+
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __builtin_assume(wave >= 0 && wave < NWAVES);
   const int cx = wave & 1, ty = (wave >> 1) & 1, tx = wave >> 2;
-  const int nblk = gridDim.x;
-  int vb = blockIdx.x;
-  if ((nblk & 7) == 0) vb = (vb & 7) * (nblk >> 3) + (vb >> 3);
-  const int bx = vb % nbx;
-  const int by = (vb / nbx) % nby;
+  const int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = vb % nbx, by = (vb / nbx) % nby;
   int bz = vb / (nbx * nby);
   const int cy = bz & 1;
   bz >>= 1;
@@ -327,9 +353,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
   const int oyl = n >> 2, oxl = n & 3;
   const int row8 = ty * TP + oyl;
   // B fragment: column term of the LDS address and the dx' of K-step 0 (k-th window column)
-  const int b_col = 2 * (tx * TP + oxl) + cx;
+  const int b_col = S * (tx * TP + oxl) + cx;
   const int dx0 = wrt1 ? (oxl + 2 * R - k) : (k - oxl);   // dx' at K-step s is dx0 -/+ 4*s
-  const int a_off = (cx * CW + n) * ACS + tx * TP + k;    // + mt*16*ACS + 4*s
+  const int a_off = n * ACS + S * (tx * TP + k) + cx;     // + mt*16*ACS + 8*s
 
   for (int cg = 0; cg < C; cg += CW) {
     const int nmt = min(MT, (C - cg + 15) / 16);
@@ -339,75 +365,97 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
     unsigned a_voff[A_PER_WAVE];
 #pragma unroll
     for (int j = 0; j < A_PER_WAVE; ++j) {
-      const int slot = (wave + NWAVES * j) * PIECE + lane;
-      const int scx = slot / (CW * ACS), r = slot - scx * (CW * ACS);
-      const int c = r / ACS, col = r - c * ACS;
-      const int X = S * (xs0 - R + col) + scx;
-      a_voff[j] = (col < LW && X >= 0 && X < W && cg + c < C) ? (unsigned)((c * plane + X) * 4) : OOB;
+      const int f = ((wave + NWAVES * j) * 64 + lane) * VA;
+      const int c = f / ACS, x = f - c * ACS;
+      const int X = S * (xs0 - R) + x;
+      a_voff[j] = (f < A_STAGE && x < ROWF && X >= 0 && X < W && cg + c < C) ? (unsigned)((c * plane + X) * 4) : OOB;
     }
 
     f32x4 acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto issue = [&](int r, float *stage) {
-      // ---- A: window row r of the other input, all channels, both column classes
-      const int Y = S * (ys0 - R + r) + cy;
-      const bool rowok = Y >= 0 && Y < H;
-      const int soff = rowok ? Y * W * 4 : 0;
+    // DMA of window row r into `stage`, in KSTEPS slices so that it can be
+    // interleaved with the K-steps of the previous row.
+    int Yr = 0, soff = 0;
+    bool rowok = false;
+    auto bind_row = [&](int r) {
+      Yr = S * (ys0 - R + r) + cy;
+      rowok = Yr >= 0 && Yr < H;
+      soff = rowok ? Yr * W * 4 : 0;
+    };
+    auto issue_slice = [&](auto SL, int r, float *stage) {
+      constexpr int sl = decltype(SL)::value;
 #pragma unroll
-      for (int j = 0; j < A_PER_WAVE; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, stage + (wave + NWAVES * j) * PIECE, 4,
-                                                 (int)(rowok ? a_voff[j] : OOB), soff, 0, 0);
-      // ---- top segments that pair with window row r: [row8][dx'][16 columns]
-#pragma unroll
-      for (int j = 0; j < T_PER_WAVE; ++j) {
-        const int pc = wave + NWAVES * j;
-        if (pc < T_PIECES) {
-          const int slot = pc * PIECE + lane;
-          const int tr = slot / (GW * S * RX), rem = slot - tr * (GW * S * RX);
-          const int dxp = rem / (S * RX), col = rem - dxp * (S * RX);
-          int dyp, Yt, Xt;
-          if (wrt1) {   // position = window position w: row r, column shifted by -dx
-            dyp = tr - r + 2 * R;
-            Yt = Y;
-            Xt = S * xs0 - S * (dxp - R) + col;
-          } else {      // position = output position o: region row tr
-            dyp = r - tr;
-            Yt = S * (ys0 + tr) + cy;
-            Xt = S * xs0 + col;
-          }
-          const bool ok = dyp >= 0 && dyp <= 2 * R && Yt >= 0 && Yt < H && Xt >= 0 && Xt < W;
-          const unsigned voff = ok ? (unsigned)((((long long)(dyp * GW + dxp) * H + Yt) * W + Xt) * 4) : OOB;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rtop, stage + A_STAGE + pc * PIECE, 4, (int)voff, 0, 0, 0);
-        }
+      for (int j = sl * APS; j < (sl + 1) * APS; ++j) {
+        if (j < A_PER_WAVE && wave + NWAVES * j < A_PIECES)
+          dma<VA>(rin, stage + (wave + NWAVES * j) * A_PIECE, rowok ? a_voff[j < A_PER_WAVE ? j : 0] : OOB, soff);
       }
+      auto top_piece = [&](auto V) {
+        constexpr int v = decltype(V)::value;
+        constexpr int pieces = T_STAGE / (64 * v), per_wave = (pieces + NWAVES - 1) / NWAVES;
+        if constexpr (sl < per_wave) {
+          const int pc = wave + NWAVES * sl;
+          if (pc < pieces) {
+            const int f = (pc * 64 + lane) * v;
+            const int tr = f / (GW * RW), rem = f - tr * (GW * RW);
+            const int dxp = rem / RW, col = rem - dxp * RW;
+            int dyp, Yt, Xt;
+            if (wrt1) {   // position = window position w: row r, column shifted by -dx
+              dyp = tr - r + 2 * R;
+              Yt = Yr;
+              Xt = S * xs0 - S * (dxp - R) + col;
+            } else {      // position = output position o: region row tr
+              dyp = r - tr;
+              Yt = S * (ys0 + tr) + cy;
+              Xt = S * xs0 + col;
+            }
+            const bool ok = f < T_IMAGE && dyp >= 0 && dyp <= 2 * R && Yt >= 0 && Yt < H && Xt >= 0 && Xt < W;
+            const unsigned voff = ok ? (unsigned)((((long long)(dyp * GW + dxp) * H + Yt) * W + Xt) * 4) : OOB;
+            dma<v>(rtop, stage + A_STAGE + pc * 64 * v, voff, 0);
+          }
+        }
+      };
+      if (VT == 4 && !wrt1) top_piece(Int<4>{});
+      else top_piece(Int<1>{});
+    };
+    auto issue_row = [&](int r, float *stage) {
+      issue_slice(Int<0>{}, r, stage); issue_slice(Int<1>{}, r, stage); issue_slice(Int<2>{}, r, stage);
+      issue_slice(Int<3>{}, r, stage); issue_slice(Int<4>{}, r, stage); issue_slice(Int<5>{}, r, stage);
     };
 
-    issue(0, lds);
+    bind_row(0);
+    issue_row(0, lds);
     __syncthreads();
     for (int r = 0; r < LH; ++r) {
       const float *cur = lds + (r & 1) * BW_STAGE;
-      if (r + 1 < LH) issue(r + 1, lds + ((r + 1) & 1) * BW_STAGE);
+      float *nxt = lds + ((r + 1) & 1) * BW_STAGE;
+      const bool more = r + 1 < LH;
+      if (more) bind_row(r + 1);
       // this wave's tile sees window rows [4*ty, 4*ty + 24)
       if (r >= ty * TP && r < ty * TP + WIN) {
         const int dyp = wrt1 ? (row8 - r + 2 * R) : (r - row8);
         const bool dyok = dyp >= 0 && dyp <= 2 * R;
-        const float *tp = cur + A_STAGE + row8 * (GW * S * RX) + b_col;
-#pragma unroll
-        for (int s4 = 0; s4 < WIN / 4; ++s4) {
+        const float *tp = cur + A_STAGE + row8 * (GW * RW) + b_col;
+        auto kstep = [&](auto S4) {
+          constexpr int s4 = decltype(S4)::value;
           const int dxp = wrt1 ? dx0 - 4 * s4 : dx0 + 4 * s4;
           const bool ok = dyok && dxp >= 0 && dxp <= 2 * R;
-          const float bv = tp[min(max(dxp, 0), 2 * R) * (S * RX)];
+          const float bv = tp[min(max(dxp, 0), 2 * R) * RW];
           const float b = ok ? bv : 0.f;
-          const float *ap = cur + a_off + 4 * s4;
+          const float *ap = cur + a_off + 4 * S * s4;
           float a[MT];
 #pragma unroll
           for (int m = 0; m < MT; ++m) a[m] = ap[m * 16 * ACS];
 #pragma unroll
           for (int m = 0; m < MT; ++m)
             if (m < nmt) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[m], 0, 0, 0);
-        }
+          if (more) issue_slice(S4, r + 1, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
+      } else if (more) {
+        issue_row(r + 1, nxt);
       }
       __syncthreads();
     }
@@ -417,7 +465,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
     const float inv = 1.f / (float)C;
     const bool pow2 = (C & (C - 1)) == 0;
     float *ob = lds;
-    constexpr int RW = S * RX;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -453,11 +500,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
   }
 }
 
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <typename K>
+int reserve_lds(K kernel, size_t smem, const char *what) {
+  // > 64 KiB of dynamic LDS needs an opt-in: once per kernel (thread-safe static; smem is a constant of K)
+  static const hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (st != hipSuccess)
+    return fail(UNFLOW_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS", what, smem);
+  return UNFLOW_OK;
+}
+
 }  // namespace
 
 bool corr_mfma_supported(const CorrGeometry &g, int C) {
+  // buffer descriptors address one image pair with 32-bit offsets
   return C > 0 && g.kernel_size == 1 && g.stride_1 == 1 && g.stride_2 == S && g.max_displacement == S * R &&
-         g.pad == g.max_displacement;
+         g.pad == g.max_displacement && (long long)C * g.H * g.W * 4 < (1LL << 31);
+}
+
+bool corr_mfma_bwd_supported(const CorrGeometry &g, int C) {
+  return corr_mfma_supported(g, C) && (long long)(GW * GW) * g.H * g.W * 4 < (1LL << 31);
 }
 
 int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, const CorrGeometry &g,
@@ -467,19 +531,16 @@ int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, 
   const int nbx = (ws + RX - 1) / RX, nby = (hs + RY - 1) / RY;
   const dim3 grid(nbx * nby * B * S);
   const size_t smem = sizeof(float) * 2 * STAGE;
-  // > 64 KiB of dynamic LDS needs an opt-in; thread-safe one-time initialisation
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(corr_mfma_fwd_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  if (attr != hipSuccess) return fail(UNFLOW_ERR_LAUNCH, "correlation_fwd (mfma): cannot reserve %zu B of LDS", smem);
-  static const int dbg = getenv("UNFLOW_CORR_DBG") ? atoi(getenv("UNFLOW_CORR_DBG")) : 0;
-  hipLaunchKernelGGL(corr_mfma_fwd_kernel, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby, dbg);
+  // 16-byte DMA segments need 16-byte aligned rows
+  const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1);
+  if (wide) {
+    if (int rc = reserve_lds(corr_mfma_fwd_kernel<4>, smem, "correlation_fwd (mfma)")) return rc;
+    hipLaunchKernelGGL(corr_mfma_fwd_kernel<4>, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby);
+  } else {
+    if (int rc = reserve_lds(corr_mfma_fwd_kernel<1>, smem, "correlation_fwd (mfma)")) return rc;
+    hipLaunchKernelGGL(corr_mfma_fwd_kernel<1>, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby);
+  }
   return launch_status("correlation_fwd (mfma)");
-}
-
-bool corr_mfma_bwd_supported(const CorrGeometry &g, int C) {
-  // buffer descriptors address one image pair with 32-bit offsets
-  return corr_mfma_supported(g, C) && (long long)(GW * GW) * g.H * g.W * 4 < (1LL << 31) &&
-         (long long)C * g.H * g.W * 4 < (1LL << 31);
 }
 
 int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,
@@ -489,11 +550,16 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
   const int nbx = (ws + RX - 1) / RX, nby = (hs + RY - 1) / RY;
   const dim3 grid(nbx * nby * B * S * 2);   // x2: gradient wrt input 0 and wrt input 1
   const size_t smem = sizeof(float) * 2 * BW_STAGE;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(corr_mfma_bwd_kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  if (attr != hipSuccess) return fail(UNFLOW_ERR_LAUNCH, "correlation_bwd (mfma): cannot reserve %zu B of LDS", smem);
-  hipLaunchKernelGGL(corr_mfma_bwd_kernel, grid, dim3(NTHREADS), smem, s, topdiff, in0, in1, g0, g1, C, H, W, nbx,
-                     nby);
+  const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(topdiff);
+  if (wide) {
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<4, 4>, smem, "correlation_bwd (mfma)")) return rc;
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<4, 4>), grid, dim3(NTHREADS), smem, s, topdiff, in0, in1, g0, g1, C, H, W,
+                       nbx, nby);
+  } else {
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<1, 1>, smem, "correlation_bwd (mfma)")) return rc;
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<1, 1>), grid, dim3(NTHREADS), smem, s, topdiff, in0, in1, g0, g1, C, H, W,
+                       nbx, nby);
+  }
   return launch_status("correlation_bwd (mfma)");
 }
 
