@@ -1,5 +1,5 @@
 # usage: bash tools/pmc_corr.sh <what: fwd|bwd> ; collects PMC passes for the correlation kernels
-what=${1:-fwd}
+what=${1:-fwd}; tag=$(echo $what | tr -d " ")
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 i=0
@@ -8,6 +8,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
            "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 5 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_${what}_$i -- python $R/tools/corr_only.py 32 $what 2 > $R/gpurun_out/pmc_${what}_$i.log 2>&1; echo "pass $i done"
+  timeout -k 5 120 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmc_${tag}_$i -- python $R/tools/corr_only.py 32 "$what" 2 > $R/gpurun_out/pmc_${tag}_$i.log 2>&1; echo "pass $i done"
 done
-cd $R && python tools/pmc_summary.py gpurun_out/pmc_${what}_*/
+cd $R && python tools/pmc_summary.py gpurun_out/pmc_${tag}_*/

@@ -294,196 +294,232 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
 // correlation position lies inside the image").  Per 4x4 tile of class positions
 // o:  G[16 channels x 16 o] += A[16 channels x 4 w] * B[4 w x 16 o]  with
 // A = the other input's window (from LDS) and B = top gathered by displacement.
-// One workgroup = 8 waves = {cx} x 2x2 tiles (as in the forward kernel) and all
-// channels (16 M-tiles of 16, 64 accumulator registers per wave); the K loop
-// walks the 28 window rows, one row (56 floats x 256 channels, plus the 8 x 21
-// top segments that pair with it) per LDS stage.
+//
+// Row sweep.  A workgroup owns a strip of 8 class columns (16 full-resolution
+// columns, both column classes) of one (pair, row class, gradient, 128-channel
+// group) and walks the class rows w = 0 .. hs-1 of the OTHER input top to bottom.
+// Row w is staged once (LDS-DMA, double buffered): A = 128 channels x 56 floats,
+// plus the top segments that pair it with every output row within +-10 rows
+// ([21 rows][21 dx][16 columns]).  It contributes to the <= 6 tiles whose rows
+// lie within +-10 of w; those tiles' accumulators stay in registers -- a ring
+// of 3 tiles per wave (8 waves = {cx} x {2 column tiles} x {tile parity}), 8
+// M-tiles of 16 channels each, 96 accumulator VGPRs -- and a finished tile is
+// regrouped through LDS and stored as 64-byte row segments.  Compared with
+// staging the whole window per 8-row region this moves 3.5x less data into LDS,
+// never touches window rows outside the image, and reads each A fragment once
+// for up to three tiles.
 // ===========================================================================
-constexpr int MT = 16;                         // M-tiles (of 16 channels) per pass
-constexpr int CW = MT * 16;                    // 256 channels per pass
-constexpr int ACS = ROWF + 4;                  // 60: channel stride of the A image (4 pad floats)
+constexpr int MTS = 8;                          // M-tiles (of 16 channels) per workgroup
+constexpr int CWS = MTS * 16;                   // 128 channels per workgroup
+constexpr int ACS = ROWF + 4;                   // 60: channel stride of the A image (4 pad floats)
 // A fragment (16 channels x 2 window columns per half): c*60 mod 32 walks the 8
 // multiples of 4 twice, +2k takes the other even banks: 2-way (see forward note).
 static_assert(ACS % 8 == 4, "A image channel stride must be 4*odd");
-constexpr int A_STAGE = CW * ACS;              // 15360 floats
-constexpr int T_IMAGE = RY * GW * RW;          // 2688 floats: [row 8][dx' 21][16 columns]
-constexpr int T_STAGE = (T_IMAGE + 255) / 256 * 256;  // 2816: padded to whole 1-KiB DMA pieces
-constexpr int BW_STAGE = A_STAGE + T_STAGE;    // 18176 floats = 71 KB
-constexpr int OUT_HALF = (CW / 2) * RY * RW;   // epilogue image of 128 channels
-static_assert(OUT_HALF <= 2 * BW_STAGE, "epilogue image must fit the staging buffers");
-constexpr int KSTEPS = WIN / 4;                // 6 K-steps per window row and tile
+constexpr int SA_STAGE = CWS * ACS;             // 7680 floats
+constexpr int TROWS = 2 * R + 1;                // 21 output rows pair with one window row
+constexpr int ST_IMAGE = TROWS * GW * RW;       // 7056 floats: [row 21][dx' 21][16 columns]
+constexpr int ST_STAGE = (ST_IMAGE + 255) / 256 * 256;   // 7168: whole 1-KiB DMA pieces
+constexpr int SW_STAGE = SA_STAGE + ST_STAGE;   // 14848 floats = 58 KB
+constexpr int SW_OUT = CWS * TP * RW;           // 8192 floats: epilogue image [channel][row 4][16 columns]
+constexpr int SW_LDS = 2 * SW_STAGE + SW_OUT;   // 37888 floats = 148 KB
+constexpr int KSTEPS = WIN / 4;                 // 6 K-steps per window row and tile
+constexpr int RING = 3;                         // live tiles per wave
 
 template <int VA, int VT>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float *__restrict__ topdiff,
                                                                     const float *__restrict__ in0,
                                                                     const float *__restrict__ in1,
                                                                     float *__restrict__ g0, float *__restrict__ g1,
-                                                                    int C, int H, int W, int nbx, int nby) {
+                                                                    int C, int H, int W, int nbx, int nch) {
   // VT: DMA width of the top segments of the gradient wrt input 0 (whole, aligned
   // 64-byte segments).  For the gradient wrt input 1 the segments are shifted by
   // the displacement (8-byte aligned only), so they always move as dwords.
   constexpr int A_PIECE = 64 * VA;
-  static_assert(A_STAGE % A_PIECE == 0 && T_STAGE % (64 * VT) == 0, "stage must split into wave pieces");
-  constexpr int A_PIECES = A_STAGE / A_PIECE;
+  static_assert(SA_STAGE % A_PIECE == 0 && ST_STAGE % (64 * VT) == 0, "stage must split into wave pieces");
+  constexpr int A_PIECES = SA_STAGE / A_PIECE;
   constexpr int A_PER_WAVE = (A_PIECES + NWAVES - 1) / NWAVES;
   constexpr int APS = (A_PER_WAVE + KSTEPS - 1) / KSTEPS;   // A pieces issued per K-step
-  static_assert((T_STAGE / 64 + NWAVES - 1) / NWAVES <= KSTEPS, "one top piece per K-step must cover the stage");
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   __builtin_assume(wave >= 0 && wave < NWAVES);
-  const int cx = wave & 1, ty = (wave >> 1) & 1, tx = wave >> 2;
-  const int vb = xcd_remap(blockIdx.x, gridDim.x);
-  const int bx = vb % nbx, by = (vb / nbx) % nby;
-  int bz = vb / (nbx * nby);
-  const int cy = bz & 1;
-  bz >>= 1;
-  const bool wrt1 = bz & 1;                    // false: gradient wrt input 0, true: wrt input 1
-  const long long item = bz >> 1;
-  const int ys0 = by * RY, xs0 = bx * RX;
-  const int hs = (H - cy + S - 1) / S;
-  if (ys0 >= hs) return;
+  const int cx = wave & 1, tx = (wave >> 1) & 1, ph = wave >> 2;
+  int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = vb % nbx;
+  vb /= nbx;
+  const int chg = vb % nch;
+  vb /= nch;
+  const bool wrt1 = vb & 1;                    // false: gradient wrt input 0, true: wrt input 1
+  const int cy = (vb >> 1) & 1;
+  const long long item = vb >> 2;
+  const int xs0 = bx * RX;
+  const int hs = (H - cy + S - 1) / S;         // class rows of this row class
+  if (hs <= 0) return;
+  const int ntiles = (hs + TP - 1) / TP;
+  const int c0 = chg * CWS;
+  const int nmt = min(MTS, (C - c0 + 15) / 16);
   const long long plane = (long long)H * W;
   const float *fin = wrt1 ? in0 : in1;         // the input the window is read from
   float *gout = wrt1 ? g1 : g0;
   const __amdgpu_buffer_rsrc_t rtop = make_rsrc(topdiff + item * (GW * GW) * plane, (unsigned)(GW * GW * plane * 4));
+  const __amdgpu_buffer_rsrc_t rin =
+      make_rsrc(fin + (item * C + c0) * plane, (unsigned)((long long)(C - c0) * plane * 4));
 
   const int k = lane >> 4, n = lane & 15;
   const int oyl = n >> 2, oxl = n & 3;
-  const int row8 = ty * TP + oyl;
   // B fragment: column term of the LDS address and the dx' of K-step 0 (k-th window column)
   const int b_col = S * (tx * TP + oxl) + cx;
   const int dx0 = wrt1 ? (oxl + 2 * R - k) : (k - oxl);   // dx' at K-step s is dx0 -/+ 4*s
   const int a_off = n * ACS + S * (tx * TP + k) + cx;     // + mt*16*ACS + 8*s
 
-  for (int cg = 0; cg < C; cg += CW) {
-    const int nmt = min(MT, (C - cg + 15) / 16);
-    const __amdgpu_buffer_rsrc_t rin =
-        make_rsrc(fin + (item * C + cg) * plane, (unsigned)((long long)(C - cg) * plane * 4));
-    // loop-invariant part of the A-stage offsets: channel plane + column, or OOB
-    unsigned a_voff[A_PER_WAVE];
+  // loop-invariant part of the A-stage offsets: channel plane + column, or OOB
+  unsigned a_voff[A_PER_WAVE];
 #pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) {
-      const int f = ((wave + NWAVES * j) * 64 + lane) * VA;
-      const int c = f / ACS, x = f - c * ACS;
-      const int X = S * (xs0 - R) + x;
-      a_voff[j] = (f < A_STAGE && x < ROWF && X >= 0 && X < W && cg + c < C) ? (unsigned)((c * plane + X) * 4) : OOB;
+  for (int j = 0; j < A_PER_WAVE; ++j) {
+    const int f = ((wave + NWAVES * j) * 64 + lane) * VA;
+    const int c = f / ACS, x = f - c * ACS;
+    const int X = S * (xs0 - R) + x;
+    a_voff[j] = (f < SA_STAGE && x < ROWF && X >= 0 && X < W && c0 + c < C) ? (unsigned)((c * plane + X) * 4) : OOB;
+  }
+
+  f32x4 acc[RING][MTS];
+#pragma unroll
+  for (int sl = 0; sl < RING; ++sl)
+#pragma unroll
+    for (int m = 0; m < MTS; ++m) acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // DMA of window row w into `stage`, in KSTEPS slices so that it can be
+  // interleaved with the K-steps of the previous row.
+  auto issue_slice = [&](auto SL, int w, float *stage) {
+    constexpr int sl = decltype(SL)::value;
+    const int Yw = S * w + cy;                 // always inside the image: 0 <= w < hs
+    const int soff = Yw * W * 4;
+#pragma unroll
+    for (int j = sl * APS; j < (sl + 1) * APS; ++j) {
+      if (j < A_PER_WAVE && wave + NWAVES * j < A_PIECES)
+        dma<VA>(rin, stage + (wave + NWAVES * j) * A_PIECE, a_voff[j < A_PER_WAVE ? j : 0], soff);
     }
-
-    f32x4 acc[MT];
+    auto top_pieces = [&](auto V) {
+      constexpr int v = decltype(V)::value;
+      constexpr int pieces = ST_STAGE / (64 * v), per_wave = (pieces + NWAVES - 1) / NWAVES;
+      constexpr int tps = (per_wave + KSTEPS - 1) / KSTEPS;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // DMA of window row r into `stage`, in KSTEPS slices so that it can be
-    // interleaved with the K-steps of the previous row.
-    int Yr = 0, soff = 0;
-    bool rowok = false;
-    auto bind_row = [&](int r) {
-      Yr = S * (ys0 - R + r) + cy;
-      rowok = Yr >= 0 && Yr < H;
-      soff = rowok ? Yr * W * 4 : 0;
-    };
-    auto issue_slice = [&](auto SL, int r, float *stage) {
-      constexpr int sl = decltype(SL)::value;
-#pragma unroll
-      for (int j = sl * APS; j < (sl + 1) * APS; ++j) {
-        if (j < A_PER_WAVE && wave + NWAVES * j < A_PIECES)
-          dma<VA>(rin, stage + (wave + NWAVES * j) * A_PIECE, rowok ? a_voff[j < A_PER_WAVE ? j : 0] : OOB, soff);
+      for (int j = sl * tps; j < (sl + 1) * tps; ++j) {
+        const int pc = wave + NWAVES * j;
+        if (j < per_wave && pc < pieces) {
+          const int f = (pc * 64 + lane) * v;
+          const int orow = f / (GW * RW), rem = f - orow * (GW * RW);
+          const int dxp = rem / RW, col = rem - dxp * RW;
+          const int oy = w - R + orow;           // output row this segment belongs to
+          int dyp, Yt, Xt;
+          if (wrt1) {   // position = window position: row w, column shifted by -dx
+            dyp = orow;                          // oy - w + R
+            Yt = Yw;
+            Xt = S * xs0 - S * (dxp - R) + col;
+          } else {      // position = output position: row oy
+            dyp = 2 * R - orow;                  // w - oy + R
+            Yt = S * oy + cy;
+            Xt = S * xs0 + col;
+          }
+          const bool ok = f < ST_IMAGE && oy >= 0 && oy < hs && Xt >= 0 && Xt < W;
+          const unsigned voff = ok ? (unsigned)((((long long)(dyp * GW + dxp) * H + Yt) * W + Xt) * 4) : OOB;
+          dma<v>(rtop, stage + SA_STAGE + pc * 64 * v, voff, 0);
+        }
       }
-      auto top_piece = [&](auto V) {
-        constexpr int v = decltype(V)::value;
-        constexpr int pieces = T_STAGE / (64 * v), per_wave = (pieces + NWAVES - 1) / NWAVES;
-        if constexpr (sl < per_wave) {
-          const int pc = wave + NWAVES * sl;
-          if (pc < pieces) {
-            const int f = (pc * 64 + lane) * v;
-            const int tr = f / (GW * RW), rem = f - tr * (GW * RW);
-            const int dxp = rem / RW, col = rem - dxp * RW;
-            int dyp, Yt, Xt;
-            if (wrt1) {   // position = window position w: row r, column shifted by -dx
-              dyp = tr - r + 2 * R;
-              Yt = Yr;
-              Xt = S * xs0 - S * (dxp - R) + col;
-            } else {      // position = output position o: region row tr
-              dyp = r - tr;
-              Yt = S * (ys0 + tr) + cy;
-              Xt = S * xs0 + col;
+    };
+    if (VT == 4 && !wrt1) top_pieces(Int<4>{});
+    else top_pieces(Int<1>{});
+  };
+  auto issue_row = [&](int w, float *stage) {
+    issue_slice(Int<0>{}, w, stage); issue_slice(Int<1>{}, w, stage); issue_slice(Int<2>{}, w, stage);
+    issue_slice(Int<3>{}, w, stage); issue_slice(Int<4>{}, w, stage); issue_slice(Int<5>{}, w, stage);
+  };
+
+  // Tile t = 2u + ph of this wave's parity lives in ring slot u % 3 while
+  // 4t - 10 <= w <= 4t + 13.
+  auto tile_in_slot = [&](int slot, int w) -> int {
+    const int num = w - 4 * ph + R;            // u_hi = floor(num / 8), num may be negative
+    const int u_hi = num >= 0 ? num / 8 : -1;
+    const int back = ((u_hi - slot) % RING + RING) % RING;
+    const int u = u_hi - back;
+    const int t = 2 * u + ph;
+    return (u >= 0 && t < ntiles && w <= 4 * t + TP - 1 + R) ? t : -1;
+  };
+
+  issue_row(0, lds);
+  __syncthreads();
+  for (int w = 0; w < hs; ++w) {
+    const float *cur = lds + (w & 1) * SW_STAGE;
+    float *nxt = lds + ((w + 1) & 1) * SW_STAGE;
+    const bool more = w + 1 < hs;
+    int tile[RING];
+#pragma unroll
+    for (int sl = 0; sl < RING; ++sl) tile[sl] = tile_in_slot(sl, w);
+
+    auto kstep = [&](auto S4) {
+      constexpr int s4 = decltype(S4)::value;
+      const float *ap = cur + a_off + 4 * S * s4;
+      float a[MTS];
+#pragma unroll
+      for (int m = 0; m < MTS; ++m) a[m] = ap[m * 16 * ACS];
+      const int dxp = wrt1 ? dx0 - 4 * s4 : dx0 + 4 * s4;
+      const bool dxok = dxp >= 0 && dxp <= 2 * R;
+      const int dxc = min(max(dxp, 0), 2 * R);
+#pragma unroll
+      for (int sl = 0; sl < RING; ++sl) {
+        if (tile[sl] >= 0) {                       // wave-uniform
+          const int orow = 4 * tile[sl] + oyl - w + R;   // row of the top image that pairs (w, this output row)
+          const bool ok = dxok && orow >= 0 && orow <= 2 * R;
+          const float bv = cur[SA_STAGE + (min(max(orow, 0), 2 * R) * GW + dxc) * RW + b_col];
+          const float b = ok ? bv : 0.f;
+#pragma unroll
+          for (int m = 0; m < MTS; ++m)
+            if (m < nmt) acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[sl][m], 0, 0, 0);
+        }
+      }
+      if (more) issue_slice(S4, w + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
+    __syncthreads();
+
+    // ---- tiles whose last window row was w: regroup through LDS to
+    // [channel][row 4][16 columns] and store 64-byte row segments.
+    const int t_lo = max(0, (w - (TP - 1) - R + TP - 1) / TP);   // first tile that can still be live
+    for (int t = t_lo; t < ntiles && 4 * t - R <= w; ++t) {
+      const int fin_row = min(hs - 1, 4 * t + TP - 1 + R);
+      if (fin_row != w) continue;                  // uniform over the workgroup
+      float *ob = lds + 2 * SW_STAGE;
+      if ((t & 1) == ph) {
+        const float inv = 1.f / (float)C;
+        const bool pow2 = (C & (C - 1)) == 0;
+        const int slot = (t >> 1) % RING;
+#pragma unroll
+        for (int sl = 0; sl < RING; ++sl) {
+          if (sl == slot) {
+#pragma unroll
+            for (int m = 0; m < MTS; ++m) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int cl = m * 16 + 4 * k + j;
+                const float v = acc[sl][m][j];
+                ob[(cl * TP + oyl) * RW + b_col] = pow2 ? v * inv : v / (float)C;
+                acc[sl][m][j] = 0.f;
+              }
             }
-            const bool ok = f < T_IMAGE && dyp >= 0 && dyp <= 2 * R && Yt >= 0 && Yt < H && Xt >= 0 && Xt < W;
-            const unsigned voff = ok ? (unsigned)((((long long)(dyp * GW + dxp) * H + Yt) * W + Xt) * 4) : OOB;
-            dma<v>(rtop, stage + A_STAGE + pc * 64 * v, voff, 0);
           }
         }
-      };
-      if (VT == 4 && !wrt1) top_piece(Int<4>{});
-      else top_piece(Int<1>{});
-    };
-    auto issue_row = [&](int r, float *stage) {
-      issue_slice(Int<0>{}, r, stage); issue_slice(Int<1>{}, r, stage); issue_slice(Int<2>{}, r, stage);
-      issue_slice(Int<3>{}, r, stage); issue_slice(Int<4>{}, r, stage); issue_slice(Int<5>{}, r, stage);
-    };
-
-    bind_row(0);
-    issue_row(0, lds);
-    __syncthreads();
-    for (int r = 0; r < LH; ++r) {
-      const float *cur = lds + (r & 1) * BW_STAGE;
-      float *nxt = lds + ((r + 1) & 1) * BW_STAGE;
-      const bool more = r + 1 < LH;
-      if (more) bind_row(r + 1);
-      // this wave's tile sees window rows [4*ty, 4*ty + 24)
-      if (r >= ty * TP && r < ty * TP + WIN) {
-        const int dyp = wrt1 ? (row8 - r + 2 * R) : (r - row8);
-        const bool dyok = dyp >= 0 && dyp <= 2 * R;
-        const float *tp = cur + A_STAGE + row8 * (GW * RW) + b_col;
-        auto kstep = [&](auto S4) {
-          constexpr int s4 = decltype(S4)::value;
-          const int dxp = wrt1 ? dx0 - 4 * s4 : dx0 + 4 * s4;
-          const bool ok = dyok && dxp >= 0 && dxp <= 2 * R;
-          const float bv = tp[min(max(dxp, 0), 2 * R) * RW];
-          const float b = ok ? bv : 0.f;
-          const float *ap = cur + a_off + 4 * S * s4;
-          float a[MT];
-#pragma unroll
-          for (int m = 0; m < MT; ++m) a[m] = ap[m * 16 * ACS];
-#pragma unroll
-          for (int m = 0; m < MT; ++m)
-            if (m < nmt) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[m], 0, 0, 0);
-          if (more) issue_slice(S4, r + 1, nxt);
-          __builtin_amdgcn_sched_barrier(0);
-        };
-        kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
-      } else if (more) {
-        issue_row(r + 1, nxt);
       }
       __syncthreads();
-    }
-
-    // ---- epilogue: acc[m][j] = G[c = 16m + 4*(lane>>4) + j][o = n]; regroup through
-    // LDS to [channel][row 8][16 columns] and store 64-byte row segments.
-    const float inv = 1.f / (float)C;
-    const bool pow2 = (C & (C - 1)) == 0;
-    float *ob = lds;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int m = h * (MT / 2); m < (h + 1) * (MT / 2); ++m) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int cl = (m - h * (MT / 2)) * 16 + 4 * k + j;
-          const float v = acc[m][j];
-          ob[(cl * RY + row8) * RW + b_col] = pow2 ? v * inv : v / (float)C;
-        }
-      }
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < OUT_HALF / 4; idx += NTHREADS) {
+      for (int idx = threadIdx.x; idx < SW_OUT / 4; idx += NTHREADS) {
         const int c4 = idx % (RW / 4);
-        const int rr = (idx / (RW / 4)) % RY;
-        const int cl = idx / (RW / 4 * RY);
-        const int c = cg + h * (CW / 2) + cl;
-        const int y = S * (ys0 + rr) + cy, x = S * xs0 + c4 * 4;
-        if (c >= C || y >= H || x >= W) continue;
+        const int rr = (idx / (RW / 4)) % TP;
+        const int cl = idx / (RW / 4 * TP);
+        const int c = c0 + cl;
+        const int oy = 4 * t + rr;
+        const int y = S * oy + cy, x = S * xs0 + c4 * 4;
+        if (c >= C || oy >= hs || x >= W) continue;
         const float4 v = *reinterpret_cast<const float4 *>(ob + idx * 4);
         float *dst = gout + (item * C + c) * plane + (long long)y * W + x;
         if (x + 3 < W && (W & 3) == 0) {
@@ -546,19 +582,20 @@ int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, 
 int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,
                   const CorrGeometry &g, hipStream_t s) {
   const int H = g.H, W = g.W;
-  const int hs = (H + S - 1) / S, ws = (W + S - 1) / S;
-  const int nbx = (ws + RX - 1) / RX, nby = (hs + RY - 1) / RY;
-  const dim3 grid(nbx * nby * B * S * 2);   // x2: gradient wrt input 0 and wrt input 1
-  const size_t smem = sizeof(float) * 2 * BW_STAGE;
+  const int ws = (W + S - 1) / S;
+  const int nbx = (ws + RX - 1) / RX, nch = (C + CWS - 1) / CWS;
+  // one workgroup per (pair, row class, gradient, channel group, column strip)
+  const dim3 grid(nbx * nch * 2 * S * B);
+  const size_t smem = sizeof(float) * SW_LDS;
   const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(topdiff);
   if (wide) {
     if (int rc = reserve_lds(corr_mfma_bwd_kernel<4, 4>, smem, "correlation_bwd (mfma)")) return rc;
     hipLaunchKernelGGL((corr_mfma_bwd_kernel<4, 4>), grid, dim3(NTHREADS), smem, s, topdiff, in0, in1, g0, g1, C, H, W,
-                       nbx, nby);
+                       nbx, nch);
   } else {
     if (int rc = reserve_lds(corr_mfma_bwd_kernel<1, 1>, smem, "correlation_bwd (mfma)")) return rc;
     hipLaunchKernelGGL((corr_mfma_bwd_kernel<1, 1>), grid, dim3(NTHREADS), smem, s, topdiff, in0, in1, g0, g1, C, H, W,
-                       nbx, nby);
+                       nbx, nch);
   }
   return launch_status("correlation_bwd (mfma)");
 }
