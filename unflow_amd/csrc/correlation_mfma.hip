@@ -185,6 +185,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   const int a_off = F1_STAGE + k * F0PL + (ty * TP + (n >> 2)) * RW + S * (tx * TP + (n & 3)) + cx;
   const int b_off = k * PLANE + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + cx;
 
+  // N-tiles (4x4 blocks of window positions) that lie entirely in the zero
+  // padding have an all-zero B operand: their MFMAs are skipped (wave-uniform
+  // masks).  At 48x160 that is 21 % of the tiles.
+  unsigned rowmask = 0, colmask = 0;
+  {
+    const int wsx = (W - cx + S - 1) / S;      // class columns that exist for this cx
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int tyu = (wv >> 1) & 1, txu = wv >> 2, cxu = wv & 1;
+    const int wsu = (W - cxu + S - 1) / S;
+    (void)wsx;
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+      const int r0 = ys0 + tyu * TP - R + 4 * q, c0q = xs0 + txu * TP - R + 4 * q;
+      if (r0 + 3 >= 0 && r0 < hs) rowmask |= 1u << q;
+      if (c0q + 3 >= 0 && c0q < wsu) colmask |= 1u << q;
+    }
+  }
+
   using St = FwdStager<VEC>;
   St st;
   st.init(H, W, cy, ys0, xs0);
@@ -213,9 +231,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
       __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs
       auto group = [&](auto G) {
         constexpr int g = decltype(G)::value;
+        if (rowmask & (1u << g)) {
 #pragma unroll
-        for (int t = g * TQ; t < (g + 1) * TQ; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+          for (int t = g * TQ; t < (g + 1) * TQ; ++t)
+            if (colmask & (1u << (t - g * TQ)))
+              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+        }
         if (more) {
           if (kk == 0) st.template issue_range<g * PER_GROUP, PER_GROUP>(nxt);
           else st.template issue_range<(TQ + g) * PER_GROUP, PER_GROUP>(nxt);
@@ -457,30 +478,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
 #pragma unroll
     for (int sl = 0; sl < RING; ++sl) tile[sl] = tile_in_slot(sl, w);
 
-    auto kstep = [&](auto S4) {
+    // A fragments are read one K-step ahead (two register sets), so the LDS
+    // latency of step s+1 hides behind the MFMAs of step s.
+    float abuf[2][MTS];
+    auto load_a = [&](auto S4) {
       constexpr int s4 = decltype(S4)::value;
       const float *ap = cur + a_off + 4 * S * s4;
-      float a[MTS];
 #pragma unroll
-      for (int m = 0; m < MTS; ++m) a[m] = ap[m * 16 * ACS];
+      for (int m = 0; m < MTS; ++m) abuf[s4 & 1][m] = ap[m * 16 * ACS];
+    };
+    auto kstep = [&](auto S4) {
+      constexpr int s4 = decltype(S4)::value;
+      if constexpr (s4 + 1 < KSTEPS) load_a(Int<s4 + 1>{});
       const int dxp = wrt1 ? dx0 - 4 * s4 : dx0 + 4 * s4;
       const bool dxok = dxp >= 0 && dxp <= 2 * R;
       const int dxc = min(max(dxp, 0), 2 * R);
+      float bfr[RING];
+#pragma unroll
+      for (int sl = 0; sl < RING; ++sl) {
+        const int orow = 4 * tile[sl] + oyl - w + R;   // row of the top image that pairs (w, this output row)
+        const bool ok = tile[sl] >= 0 && dxok && orow >= 0 && orow <= 2 * R;
+        const float bv = cur[SA_STAGE + (min(max(orow, 0), 2 * R) * GW + dxc) * RW + b_col];
+        bfr[sl] = ok ? bv : 0.f;
+      }
 #pragma unroll
       for (int sl = 0; sl < RING; ++sl) {
         if (tile[sl] >= 0) {                       // wave-uniform
-          const int orow = 4 * tile[sl] + oyl - w + R;   // row of the top image that pairs (w, this output row)
-          const bool ok = dxok && orow >= 0 && orow <= 2 * R;
-          const float bv = cur[SA_STAGE + (min(max(orow, 0), 2 * R) * GW + dxc) * RW + b_col];
-          const float b = ok ? bv : 0.f;
 #pragma unroll
           for (int m = 0; m < MTS; ++m)
-            if (m < nmt) acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[sl][m], 0, 0, 0);
+            if (m < nmt) acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s4 & 1][m], bfr[sl], acc[sl][m], 0, 0, 0);
         }
       }
       if (more) issue_slice(S4, w + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
     };
+    load_a(Int<0>{});
     kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
     __syncthreads();
 
