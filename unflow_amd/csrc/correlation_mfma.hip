@@ -190,11 +190,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   // masks).  At 48x160 that is 21 % of the tiles.
   unsigned rowmask = 0, colmask = 0;
   {
-    const int wsx = (W - cx + S - 1) / S;      // class columns that exist for this cx
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int tyu = (wv >> 1) & 1, txu = wv >> 2, cxu = wv & 1;
-    const int wsu = (W - cxu + S - 1) / S;
-    (void)wsx;
+    const int wsu = (W - cxu + S - 1) / S;     // class columns that exist for this wave's cx
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
       const int r0 = ys0 + tyu * TP - R + 4 * q, c0q = xs0 + txu * TP - R + 4 * q;
@@ -346,20 +344,23 @@ constexpr int SW_LDS = 2 * SW_STAGE + SW_OUT;   // 37888 floats = 148 KB
 constexpr int KSTEPS = WIN / 4;                 // 6 K-steps per window row and tile
 constexpr int RING = 3;                         // live tiles per wave
 
-template <int VA, int VT>
+template <int VA, int VT, bool WRT1, int VARIANT>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float *__restrict__ topdiff,
-                                                                    const float *__restrict__ in0,
-                                                                    const float *__restrict__ in1,
-                                                                    float *__restrict__ g0, float *__restrict__ g1,
-                                                                    int C, int H, int W, int nbx, int nch) {
-  // VT: DMA width of the top segments of the gradient wrt input 0 (whole, aligned
-  // 64-byte segments).  For the gradient wrt input 1 the segments are shifted by
-  // the displacement (8-byte aligned only), so they always move as dwords.
-  constexpr int A_PIECE = 64 * VA;
-  static_assert(SA_STAGE % A_PIECE == 0 && ST_STAGE % (64 * VT) == 0, "stage must split into wave pieces");
-  constexpr int A_PIECES = SA_STAGE / A_PIECE;
+                                                                    const float *__restrict__ fin,
+                                                                    float *__restrict__ gout, int C, int H, int W,
+                                                                    int nbx, int nch) {
+  // WRT1 = false: gradient wrt input 0 (fin = input 1); true: wrt input 1 (fin = input 0).
+  // VT: DMA width of the top segments.  For the gradient wrt input 0 they are
+  // whole, aligned 64-byte segments; wrt input 1 they are shifted by the
+  // displacement (8-byte aligned only) and always move as dwords (VT = 1).
+  static_assert(!WRT1 || VT == 1, "shifted top segments move as dwords");
+  constexpr int A_PIECE = 64 * VA, T_PIECE = 64 * VT;
+  static_assert(SA_STAGE % A_PIECE == 0 && ST_STAGE % T_PIECE == 0, "stage must split into wave pieces");
+  constexpr int A_PIECES = SA_STAGE / A_PIECE, T_PIECES = ST_STAGE / T_PIECE;
   constexpr int A_PER_WAVE = (A_PIECES + NWAVES - 1) / NWAVES;
+  constexpr int T_PER_WAVE = (T_PIECES + NWAVES - 1) / NWAVES;
   constexpr int APS = (A_PER_WAVE + KSTEPS - 1) / KSTEPS;   // A pieces issued per K-step
+  constexpr int TPS = (T_PER_WAVE + KSTEPS - 1) / KSTEPS;   // top pieces issued per K-step
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
@@ -371,9 +372,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
   vb /= nbx;
   const int chg = vb % nch;
   vb /= nch;
-  const bool wrt1 = vb & 1;                    // false: gradient wrt input 0, true: wrt input 1
-  const int cy = (vb >> 1) & 1;
-  const long long item = vb >> 2;
+  const int cy = vb & 1;
+  const long long item = vb >> 1;
   const int xs0 = bx * RX;
   const int hs = (H - cy + S - 1) / S;         // class rows of this row class
   if (hs <= 0) return;
@@ -381,20 +381,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
   const int c0 = chg * CWS;
   const int nmt = min(MTS, (C - c0 + 15) / 16);
   const long long plane = (long long)H * W;
-  const float *fin = wrt1 ? in0 : in1;         // the input the window is read from
-  float *gout = wrt1 ? g1 : g0;
   const __amdgpu_buffer_rsrc_t rtop = make_rsrc(topdiff + item * (GW * GW) * plane, (unsigned)(GW * GW * plane * 4));
   const __amdgpu_buffer_rsrc_t rin =
       make_rsrc(fin + (item * C + c0) * plane, (unsigned)((long long)(C - c0) * plane * 4));
+  const int row_bytes = S * W * 4;             // one class row further down
 
   const int k = lane >> 4, n = lane & 15;
   const int oyl = n >> 2, oxl = n & 3;
-  // B fragment: column term of the LDS address and the dx' of K-step 0 (k-th window column)
-  const int b_col = S * (tx * TP + oxl) + cx;
-  const int dx0 = wrt1 ? (oxl + 2 * R - k) : (k - oxl);   // dx' at K-step s is dx0 -/+ 4*s
+  const int b_col = S * (tx * TP + oxl) + cx;  // column of this lane's output position in the region
   const int a_off = n * ACS + S * (tx * TP + k) + cx;     // + mt*16*ACS + 8*s
 
-  // loop-invariant part of the A-stage offsets: channel plane + column, or OOB
+  // Everything that does not depend on the sweep row is computed once:
+  //  * A pieces: channel plane + column (or OOB); the row is the SGPR offset
+  //  * top pieces: offset at row 0 (linear in w), the top-image row they fill
+  //  * B fragments: dx' of each K-step as an LDS offset plus its validity
   unsigned a_voff[A_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < A_PER_WAVE; ++j) {
@@ -402,6 +402,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
     const int c = f / ACS, x = f - c * ACS;
     const int X = S * (xs0 - R) + x;
     a_voff[j] = (f < SA_STAGE && x < ROWF && X >= 0 && X < W && c0 + c < C) ? (unsigned)((c * plane + X) * 4) : OOB;
+  }
+  int t_base[T_PER_WAVE];      // byte offset of the segment at sweep row 0
+  int t_orow[T_PER_WAVE];      // row of the top image (output row = w - R + orow); huge = never valid
+#pragma unroll
+  for (int j = 0; j < T_PER_WAVE; ++j) {
+    const int f = ((wave + NWAVES * j) * 64 + lane) * VT;
+    const int orow = f / (GW * RW), rem = f - orow * (GW * RW);
+    const int dxp = rem / RW, col = rem - dxp * RW;
+    int dyp, Y0, Xt;
+    if (WRT1) {   // position = window position: row w, column shifted by -dx
+      dyp = orow;                              // oy - w + R
+      Y0 = cy;
+      Xt = S * xs0 - S * (dxp - R) + col;
+    } else {      // position = output position: row oy = w - R + orow
+      dyp = 2 * R - orow;                      // w - oy + R
+      Y0 = S * (orow - R) + cy;
+      Xt = S * xs0 + col;
+    }
+    const bool ok = wave + NWAVES * j < T_PIECES && f < ST_IMAGE && Xt >= 0 && Xt < W;
+    t_base[j] = (int)((((long long)(dyp * GW + dxp) * H + Y0) * W + Xt) * 4);
+    t_orow[j] = ok ? orow : (1 << 28);
+  }
+  int b_dx[KSTEPS];            // LDS offset of dx' for K-step s (clamped), validity in b_dxok
+  unsigned b_dxok = 0;
+#pragma unroll
+  for (int q = 0; q < KSTEPS; ++q) {
+    const int dxp = WRT1 ? (oxl + 2 * R - k - 4 * q) : (k - oxl + 4 * q);
+    if (dxp >= 0 && dxp <= 2 * R) b_dxok |= 1u << q;
+    b_dx[q] = min(max(dxp, 0), 2 * R) * RW + b_col + SA_STAGE;
   }
 
   f32x4 acc[RING][MTS];
@@ -414,43 +443,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
   // interleaved with the K-steps of the previous row.
   auto issue_slice = [&](auto SL, int w, float *stage) {
     constexpr int sl = decltype(SL)::value;
-    const int Yw = S * w + cy;                 // always inside the image: 0 <= w < hs
-    const int soff = Yw * W * 4;
+    const int soff = (S * w + cy) * W * 4;     // row w is always inside the image
 #pragma unroll
     for (int j = sl * APS; j < (sl + 1) * APS; ++j) {
       if (j < A_PER_WAVE && wave + NWAVES * j < A_PIECES)
         dma<VA>(rin, stage + (wave + NWAVES * j) * A_PIECE, a_voff[j < A_PER_WAVE ? j : 0], soff);
     }
-    auto top_pieces = [&](auto V) {
-      constexpr int v = decltype(V)::value;
-      constexpr int pieces = ST_STAGE / (64 * v), per_wave = (pieces + NWAVES - 1) / NWAVES;
-      constexpr int tps = (per_wave + KSTEPS - 1) / KSTEPS;
 #pragma unroll
-      for (int j = sl * tps; j < (sl + 1) * tps; ++j) {
-        const int pc = wave + NWAVES * j;
-        if (j < per_wave && pc < pieces) {
-          const int f = (pc * 64 + lane) * v;
-          const int orow = f / (GW * RW), rem = f - orow * (GW * RW);
-          const int dxp = rem / RW, col = rem - dxp * RW;
-          const int oy = w - R + orow;           // output row this segment belongs to
-          int dyp, Yt, Xt;
-          if (wrt1) {   // position = window position: row w, column shifted by -dx
-            dyp = orow;                          // oy - w + R
-            Yt = Yw;
-            Xt = S * xs0 - S * (dxp - R) + col;
-          } else {      // position = output position: row oy
-            dyp = 2 * R - orow;                  // w - oy + R
-            Yt = S * oy + cy;
-            Xt = S * xs0 + col;
-          }
-          const bool ok = f < ST_IMAGE && oy >= 0 && oy < hs && Xt >= 0 && Xt < W;
-          const unsigned voff = ok ? (unsigned)((((long long)(dyp * GW + dxp) * H + Yt) * W + Xt) * 4) : OOB;
-          dma<v>(rtop, stage + SA_STAGE + pc * 64 * v, voff, 0);
-        }
+    for (int j = sl * TPS; j < (sl + 1) * TPS; ++j) {
+      if (j < T_PER_WAVE && wave + NWAVES * j < T_PIECES) {
+        const int jj = j < T_PER_WAVE ? j : 0;
+        const int oy = w - R + t_orow[jj];
+        const unsigned voff = (oy >= 0 && oy < hs) ? (unsigned)(t_base[jj] + w * row_bytes) : OOB;
+        dma<VT>(rtop, stage + SA_STAGE + (wave + NWAVES * j) * T_PIECE, voff, 0);
       }
-    };
-    if (VT == 4 && !wrt1) top_pieces(Int<4>{});
-    else top_pieces(Int<1>{});
+    }
   };
   auto issue_row = [&](int w, float *stage) {
     issue_slice(Int<0>{}, w, stage); issue_slice(Int<1>{}, w, stage); issue_slice(Int<2>{}, w, stage);
@@ -460,8 +467,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
   // Tile t = 2u + ph of this wave's parity lives in ring slot u % 3 while
   // 4t - 10 <= w <= 4t + 13.
   auto tile_in_slot = [&](int slot, int w) -> int {
-    const int num = w - 4 * ph + R;            // u_hi = floor(num / 8), num may be negative
-    const int u_hi = num >= 0 ? num / 8 : -1;
+    const int u_hi = (w - 4 * ph + R) / 8;     // >= 0 because w >= 0 and ph <= 1
     const int back = ((u_hi - slot) % RING + RING) % RING;
     const int u = u_hi - back;
     const int t = 2 * u + ph;
@@ -474,51 +480,52 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
     const float *cur = lds + (w & 1) * SW_STAGE;
     float *nxt = lds + ((w + 1) & 1) * SW_STAGE;
     const bool more = w + 1 < hs;
-    int tile[RING];
+    // per ring slot: live tile, LDS row offset of the top image row that pairs
+    // (w, this lane's output row), validity
+    int tile[RING], b_row[RING];
+    bool b_rowok[RING];
 #pragma unroll
-    for (int sl = 0; sl < RING; ++sl) tile[sl] = tile_in_slot(sl, w);
+    for (int sl = 0; sl < RING; ++sl) {
+      tile[sl] = tile_in_slot(sl, w);
+      const int orow = 4 * tile[sl] + oyl - w + R;
+      b_rowok[sl] = tile[sl] >= 0 && orow >= 0 && orow <= 2 * R;
+      b_row[sl] = min(max(orow, 0), 2 * R) * (GW * RW);
+    }
 
-    // A fragments are read one K-step ahead (two register sets), so the LDS
-    // latency of step s+1 hides behind the MFMAs of step s.
-    float abuf[2][MTS];
-    auto load_a = [&](auto S4) {
+    // A and B fragments are read one K-step ahead (two register sets), so the
+    // LDS latency of step s+1 hides behind the MFMAs of step s.
+    float abuf[2][MTS], bbuf[2][RING];
+    auto load_ab = [&](auto S4) {
       constexpr int s4 = decltype(S4)::value;
       const float *ap = cur + a_off + 4 * S * s4;
 #pragma unroll
       for (int m = 0; m < MTS; ++m) abuf[s4 & 1][m] = ap[m * 16 * ACS];
+#pragma unroll
+      for (int sl = 0; sl < RING; ++sl) bbuf[s4 & 1][sl] = cur[b_row[sl] + b_dx[s4]];   // masked at use
     };
     auto kstep = [&](auto S4) {
       constexpr int s4 = decltype(S4)::value;
-      if constexpr (s4 + 1 < KSTEPS) load_a(Int<s4 + 1>{});
-      const int dxp = wrt1 ? dx0 - 4 * s4 : dx0 + 4 * s4;
-      const bool dxok = dxp >= 0 && dxp <= 2 * R;
-      const int dxc = min(max(dxp, 0), 2 * R);
-      float bfr[RING];
-#pragma unroll
-      for (int sl = 0; sl < RING; ++sl) {
-        const int orow = 4 * tile[sl] + oyl - w + R;   // row of the top image that pairs (w, this output row)
-        const bool ok = tile[sl] >= 0 && dxok && orow >= 0 && orow <= 2 * R;
-        const float bv = cur[SA_STAGE + (min(max(orow, 0), 2 * R) * GW + dxc) * RW + b_col];
-        bfr[sl] = ok ? bv : 0.f;
-      }
+      if constexpr (s4 + 1 < KSTEPS) load_ab(Int<s4 + 1>{});
+      const bool dxok = b_dxok & (1u << s4);
 #pragma unroll
       for (int sl = 0; sl < RING; ++sl) {
         if (tile[sl] >= 0) {                       // wave-uniform
+          const float b = (dxok && b_rowok[sl]) ? bbuf[s4 & 1][sl] : 0.f;
 #pragma unroll
           for (int m = 0; m < MTS; ++m)
-            if (m < nmt) acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s4 & 1][m], bfr[sl], acc[sl][m], 0, 0, 0);
+            if (m < nmt) acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s4 & 1][m], b, acc[sl][m], 0, 0, 0);
         }
       }
       if (more) issue_slice(S4, w + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!(VARIANT & 1)) __builtin_amdgcn_sched_barrier(0);
     };
-    load_a(Int<0>{});
+    load_ab(Int<0>{});
     kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
     __syncthreads();
 
     // ---- tiles whose last window row was w: regroup through LDS to
     // [channel][row 4][16 columns] and store 64-byte row segments.
-    const int t_lo = max(0, (w - (TP - 1) - R + TP - 1) / TP);   // first tile that can still be live
+    const int t_lo = max(0, (w - R) / TP);         // first tile that can still be live
     for (int t = t_lo; t < ntiles && 4 * t - R <= w; ++t) {
       const int fin_row = min(hs - 1, 4 * t + TP - 1 + R);
       if (fin_row != w) continue;                  // uniform over the workgroup
@@ -616,19 +623,27 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
   const int H = g.H, W = g.W;
   const int ws = (W + S - 1) / S;
   const int nbx = (ws + RX - 1) / RX, nch = (C + CWS - 1) / CWS;
-  // one workgroup per (pair, row class, gradient, channel group, column strip)
-  const dim3 grid(nbx * nch * 2 * S * B);
+  // one workgroup per (pair, row class, channel group, column strip); one launch per gradient
+  const dim3 grid(nbx * nch * S * B);
   const size_t smem = sizeof(float) * SW_LDS;
   const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(topdiff);
+  const int var = getenv("UNFLOW_BWD_VARIANT") ? atoi(getenv("UNFLOW_BWD_VARIANT")) : 0;
+#define UNFLOW_LAUNCH(VA, VT0, V)                                                                              \
+  do {                                                                                                         \
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, false, V>, smem, "correlation_bwd (mfma)")) return rc; \
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, 1, true, V>, smem, "correlation_bwd (mfma)")) return rc;  \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, false, V>), grid, dim3(NTHREADS), smem, s, topdiff, in1, g0, C, \
+                       H, W, nbx, nch);                                                                        \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, 1, true, V>), grid, dim3(NTHREADS), smem, s, topdiff, in0, g1, C,    \
+                       H, W, nbx, nch);                                                                        \
+  } while (0)
   if (wide) {
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<4, 4>, smem, "correlation_bwd (mfma)")) return rc;
-    hipLaunchKernelGGL((corr_mfma_bwd_kernel<4, 4>), grid, dim3(NTHREADS), smem, s, topdiff, in0, in1, g0, g1, C, H, W,
-                       nbx, nch);
+    if (var & 1) UNFLOW_LAUNCH(4, 4, 1);
+    else UNFLOW_LAUNCH(4, 4, 0);
   } else {
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<1, 1>, smem, "correlation_bwd (mfma)")) return rc;
-    hipLaunchKernelGGL((corr_mfma_bwd_kernel<1, 1>), grid, dim3(NTHREADS), smem, s, topdiff, in0, in1, g0, g1, C, H, W,
-                       nbx, nch);
+    UNFLOW_LAUNCH(1, 1, 0);
   }
+#undef UNFLOW_LAUNCH
   return launch_status("correlation_bwd (mfma)");
 }
 
