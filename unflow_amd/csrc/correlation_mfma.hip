@@ -344,7 +344,7 @@ constexpr int SW_LDS = 2 * SW_STAGE + SW_OUT;   // 37888 floats = 148 KB
 constexpr int KSTEPS = WIN / 4;                 // 6 K-steps per window row and tile
 constexpr int RING = 3;                         // live tiles per wave
 
-template <int VA, int VT, bool WRT1, int VARIANT>
+template <int VA, int VT, bool WRT1>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float *__restrict__ topdiff,
                                                                     const float *__restrict__ fin,
                                                                     float *__restrict__ gout, int C, int H, int W,
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
         }
       }
       if (more) issue_slice(S4, w + 1, nxt);
-      if (!(VARIANT & 1)) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     };
     load_ab(Int<0>{});
     kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
@@ -627,22 +627,17 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
   const dim3 grid(nbx * nch * S * B);
   const size_t smem = sizeof(float) * SW_LDS;
   const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(topdiff);
-  const int var = getenv("UNFLOW_BWD_VARIANT") ? atoi(getenv("UNFLOW_BWD_VARIANT")) : 0;
-#define UNFLOW_LAUNCH(VA, VT0, V)                                                                              \
-  do {                                                                                                         \
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, false, V>, smem, "correlation_bwd (mfma)")) return rc; \
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, 1, true, V>, smem, "correlation_bwd (mfma)")) return rc;  \
-    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, false, V>), grid, dim3(NTHREADS), smem, s, topdiff, in1, g0, C, \
-                       H, W, nbx, nch);                                                                        \
-    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, 1, true, V>), grid, dim3(NTHREADS), smem, s, topdiff, in0, g1, C,    \
-                       H, W, nbx, nch);                                                                        \
+#define UNFLOW_LAUNCH(VA, VT0)                                                                                \
+  do {                                                                                                        \
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, false>, smem, "correlation_bwd (mfma)")) return rc; \
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, 1, true>, smem, "correlation_bwd (mfma)")) return rc;    \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, false>), grid, dim3(NTHREADS), smem, s, topdiff, in1, g0, C, H, \
+                       W, nbx, nch);                                                                          \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, 1, true>), grid, dim3(NTHREADS), smem, s, topdiff, in0, g1, C, H,    \
+                       W, nbx, nch);                                                                          \
   } while (0)
-  if (wide) {
-    if (var & 1) UNFLOW_LAUNCH(4, 4, 1);
-    else UNFLOW_LAUNCH(4, 4, 0);
-  } else {
-    UNFLOW_LAUNCH(1, 1, 0);
-  }
+  if (wide) UNFLOW_LAUNCH(4, 4);
+  else UNFLOW_LAUNCH(1, 1);
 #undef UNFLOW_LAUNCH
   return launch_status("correlation_bwd (mfma)");
 }
