@@ -1,0 +1,136 @@
+"""Parity at BASELINE.json's full sizes (384x1280 pairs, FlowNetC features
+[B,256,48,160]) through size-independent properties -- the CPU oracle is too slow
+to replay these sizes in a test -- plus an oracle spot check on one full-size
+sample.  All through the C ABI."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+H, W, C8, H8, W8 = 384, 1280, 256, 48, 160
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    return torch.device("cuda:0")
+
+
+def gen(dev, seed):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    return g
+
+
+def test_correlation_properties_cfg2(dev):
+    """cfg2: B=8, [8,256,48,160].  Linearity in each argument, the zero-displacement
+    plane equals mean_c(f0*f1), and a shifted copy peaks on the matching plane."""
+    from unflow_amd import ops
+    g = gen(dev, 1)
+    f0 = torch.randn((8, C8, H8, W8), device=dev, generator=g)
+    f1 = torch.randn((8, C8, H8, W8), device=dev, generator=g)
+    c = ops.correlation(f0, f1)
+    assert c.shape == (8, 441, H8, W8)
+    # bilinear: exact for power-of-two scales
+    assert torch.equal(ops.correlation(2 * f0, f1), 2 * c)
+    assert torch.equal(ops.correlation(f0, 0.5 * f1), 0.5 * c)
+    f2 = torch.randn_like(f1)
+    torch.testing.assert_close(ops.correlation(f0, f1 + f2), c + ops.correlation(f0, f2), rtol=1e-5, atol=1e-5)
+    # centre plane (dy=dx=0) is the channel mean of the product
+    torch.testing.assert_close(c[:, 220], (f0.double() * f1.double()).mean(1).float(), rtol=1e-5, atol=1e-5)
+    # f1 = f0 shifted by (dy, dx) = (+4, -6): plane of displacement (4,-6) holds mean(f0^2) where defined
+    dy, dx = 4, -6
+    shifted = torch.zeros_like(f0)
+    shifted[:, :, dy:, :W8 + dx] = f0[:, :, :H8 - dy, -dx:]
+    cs = ops.correlation(f0, shifted)
+    plane = (dy // 2 + 10) * 21 + (dx // 2 + 10)
+    want = (f0.double() ** 2).mean(1).float()
+    torch.testing.assert_close(cs[:, plane, :H8 - dy, -dx:], want[:, :H8 - dy, -dx:], rtol=1e-5, atol=1e-5)
+
+
+def test_correlation_gradient_adjoint_cfg2(dev):
+    """<corr(f0,f1), top> differentiates to the kernels' gradients: the adjoint
+    identity <top, corr(df0, f1)> == <g0, df0> holds at full size."""
+    from unflow_amd import ops
+    g = gen(dev, 2)
+    f0 = torch.randn((4, C8, H8, W8), device=dev, generator=g)
+    f1 = torch.randn((4, C8, H8, W8), device=dev, generator=g)
+    top = torch.randn((4, 441, H8, W8), device=dev, generator=g)
+    g0, g1 = ops.correlation_grad(top, f0, f1)
+    d0 = torch.randn_like(f0)
+    d1 = torch.randn_like(f1)
+    lhs0 = (ops.correlation(d0, f1).double() * top.double()).sum()
+    lhs1 = (ops.correlation(f0, d1).double() * top.double()).sum()
+    np.testing.assert_allclose(float((g0.double() * d0.double()).sum()), float(lhs0), rtol=1e-5)
+    np.testing.assert_allclose(float((g1.double() * d1.double()).sum()), float(lhs1), rtol=1e-5)
+
+
+def test_correlation_full_size_sample_vs_oracle(oracle_mod, dev):
+    """One full-size pair against the CPU oracle (about 3 s of CPU)."""
+    from unflow_amd import ops
+    rng = np.random.default_rng(3)
+    f0 = rng.standard_normal((1, C8, H8, W8)).astype(np.float32)
+    f1 = rng.standard_normal((1, C8, H8, W8)).astype(np.float32)
+    want, p0, p1 = oracle_mod.correlation(f0, f1)
+    a, b = torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev)
+    np.testing.assert_allclose(ops.correlation(a, b).cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    top = rng.standard_normal(want.shape).astype(np.float32)
+    g0, g1 = ops.correlation_grad(torch.from_numpy(top).to(dev), a, b)
+    w0, w1 = oracle_mod.correlation_grad(top, f0, f1, p0, p1)
+    np.testing.assert_allclose(g0.cpu().numpy(), w0, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(g1.cpu().numpy(), w1, rtol=1e-5, atol=1e-5)
+
+
+def test_warps_integer_shift_cfg2(dev):
+    """An integer flow is a pure shift: exact for both warp semantics; the two differ
+    only where taps leave the image (zero vs clamp)."""
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp
+    g = gen(dev, 4)
+    im = torch.rand((8, H, W, 3), device=dev, generator=g)
+    flow = torch.zeros((8, H, W, 2), device=dev)
+    flow[..., 0], flow[..., 1] = 5.0, -3.0      # sample at (x+5, y-3)
+    bw, iw = ops.backward_warp(im, flow), image_warp(im, flow)
+    assert torch.equal(bw[:, 3:, :W - 5], im[:, :H - 3, 5:])
+    assert torch.equal(iw[:, 3:, :W - 5], im[:, :H - 3, 5:])
+    assert float(bw[:, :3].abs().max()) == 0.0 and float(bw[:, :, W - 5:].abs().max()) == 0.0
+    assert torch.equal(iw[:, :3, :W - 5], im[:, :1, 5:].expand(-1, 3, -1, -1))      # clamped rows repeat row 0
+    assert torch.equal(image_warp(im, torch.zeros_like(flow)), im)                   # idempotent at zero flow
+
+
+def test_forward_warp_mass_cfg3(dev):
+    """Every source pixel deposits (sum_d exp(-d^2/2))^2 over its window when it is
+    away from the border; a global translation keeps the interior density at 2*pi."""
+    from unflow_amd import ops
+    flow = torch.zeros((32, H, W, 2), device=dev)
+    flow[..., 0], flow[..., 1] = 7.25, -4.5
+    out = ops.forward_warp(flow)
+    s = sum(np.exp(-(d - 0.25) ** 2 / 2.0) for d in range(-4, 5)) * sum(np.exp(-(d - 0.5) ** 2 / 2.0) for d in range(-4, 5))
+    interior = out[:, 20:H - 20, 20:W - 20, 0]
+    np.testing.assert_allclose(float(interior.min()), s, rtol=2e-6)
+    np.testing.assert_allclose(float(interior.max()), s, rtol=2e-6)
+    # deterministic inside a window: two launches agree bitwise on a coherent flow
+    assert torch.equal(ops.forward_warp(flow), out)
+
+
+def test_census_properties_cfg3(dev):
+    """Identical images: distance 0 everywhere, loss = eps^(2*alpha) * mean(mask');
+    the loss is additive over a split of the batch when normalised globally."""
+    from unflow_amd import losses
+    g = gen(dev, 5)
+    im1 = torch.rand((32, H, W, 3), device=dev, generator=g)
+    im2 = torch.rand((32, H, W, 3), device=dev, generator=g)
+    mask = losses.create_border_mask(im1, 0.1)
+    l0 = losses.ternary_loss(im1, im1, mask, max_distance=3)
+    inner = float(mask.mean())        # border (39) > census border (3)
+    np.testing.assert_allclose(float(l0), (0.001 ** 2) ** 0.45 * inner, rtol=1e-5)
+    full = losses.ternary_loss(im1, im2, mask, max_distance=3)
+    npx = 32 * H * W
+    parts = [losses.ternary_loss(im1[i:i + 8], im2[i:i + 8], mask[i:i + 8], max_distance=3, norm_count=npx)
+             for i in range(0, 32, 8)]
+    np.testing.assert_allclose(float(sum(parts)), float(full), rtol=1e-5)
+    # dist_sum bounds: 0 <= D <= P*P
+    d = losses.ternary_dist(im1[:4], im2[:4], 3)
+    assert float(d.min()) >= 0.0 and float(d.max()) <= 49.0

@@ -351,16 +351,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
                                                                     int nbx, int nch) {
   // WRT1 = false: gradient wrt input 0 (fin = input 1); true: wrt input 1 (fin = input 0).
   // VT: DMA width of the top segments.  For the gradient wrt input 0 they are
-  // whole, aligned 64-byte segments; wrt input 1 they are shifted by the
-  // displacement (8-byte aligned only) and always move as dwords (VT = 1).
-  static_assert(!WRT1 || VT == 1, "shifted top segments move as dwords");
+  // whole, aligned 64-byte segments.  Wrt input 1 they are shifted by the
+  // displacement: 8-byte aligned, and a 16-byte piece may straddle the end of an
+  // image row; the floats it then picks up from the neighbouring row belong to
+  // window positions outside the image and are masked when the fragment is read
+  // (b_dxok also tests the window column), so they are never used.
   constexpr int A_PIECE = 64 * VA, T_PIECE = 64 * VT;
   static_assert(SA_STAGE % A_PIECE == 0 && ST_STAGE % T_PIECE == 0, "stage must split into wave pieces");
   constexpr int A_PIECES = SA_STAGE / A_PIECE, T_PIECES = ST_STAGE / T_PIECE;
   constexpr int A_PER_WAVE = (A_PIECES + NWAVES - 1) / NWAVES;
   constexpr int T_PER_WAVE = (T_PIECES + NWAVES - 1) / NWAVES;
-  constexpr int APS = (A_PER_WAVE + KSTEPS - 1) / KSTEPS;   // A pieces issued per K-step
-  constexpr int TPS = (T_PER_WAVE + KSTEPS - 1) / KSTEPS;   // top pieces issued per K-step
+  // the DMA of the next row is issued during the first DSL K-steps of this row,
+  // so that it has the remaining K-steps to land before the barrier
+  constexpr int DSL = (VA == 4 && VT == 4) ? 3 : KSTEPS;
+  constexpr int APS = (A_PER_WAVE + DSL - 1) / DSL;   // A pieces issued per K-step
+  constexpr int TPS = (T_PER_WAVE + DSL - 1) / DSL;   // top pieces issued per K-step
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
       Y0 = S * (orow - R) + cy;
       Xt = S * xs0 + col;
     }
-    const bool ok = wave + NWAVES * j < T_PIECES && f < ST_IMAGE && Xt >= 0 && Xt < W;
+    const bool ok = wave + NWAVES * j < T_PIECES && f < ST_IMAGE && Xt + VT - 1 >= 0 && Xt < W;
     t_base[j] = (int)((((long long)(dyp * GW + dxp) * H + Y0) * W + Xt) * 4);
     t_orow[j] = ok ? orow : (1 << 28);
   }
@@ -429,7 +434,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
 #pragma unroll
   for (int q = 0; q < KSTEPS; ++q) {
     const int dxp = WRT1 ? (oxl + 2 * R - k - 4 * q) : (k - oxl + 4 * q);
-    if (dxp >= 0 && dxp <= 2 * R) b_dxok |= 1u << q;
+    const int Xw = S * (xs0 + tx * TP - R + 4 * q + k) + cx;   // full-resolution column of the window position
+    if (dxp >= 0 && dxp <= 2 * R && (!WRT1 || (Xw >= 0 && Xw < W))) b_dxok |= 1u << q;
     b_dx[q] = min(max(dxp, 0), 2 * R) * RW + b_col + SA_STAGE;
   }
 
@@ -630,10 +636,10 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
 #define UNFLOW_LAUNCH(VA, VT0)                                                                                \
   do {                                                                                                        \
     if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, false>, smem, "correlation_bwd (mfma)")) return rc; \
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, 1, true>, smem, "correlation_bwd (mfma)")) return rc;    \
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, true>, smem, "correlation_bwd (mfma)")) return rc;    \
     hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, false>), grid, dim3(NTHREADS), smem, s, topdiff, in1, g0, C, H, \
                        W, nbx, nch);                                                                          \
-    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, 1, true>), grid, dim3(NTHREADS), smem, s, topdiff, in0, g1, C, H,    \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, true>), grid, dim3(NTHREADS), smem, s, topdiff, in0, g1, C, H,    \
                        W, nbx, nch);                                                                          \
   } while (0)
   if (wide) UNFLOW_LAUNCH(4, 4);
