@@ -344,12 +344,14 @@ constexpr int SW_LDS = 2 * SW_STAGE + SW_OUT;   // 37888 floats = 148 KB
 constexpr int KSTEPS = WIN / 4;                 // 6 K-steps per window row and tile
 constexpr int RING = 3;                         // live tiles per wave
 
-template <int VA, int VT, bool WRT1>
+template <int VA, int VT, bool WRT1, bool FULL>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float *__restrict__ topdiff,
                                                                     const float *__restrict__ fin,
                                                                     float *__restrict__ gout, int C, int H, int W,
                                                                     int nbx, int nch) {
   // WRT1 = false: gradient wrt input 0 (fin = input 1); true: wrt input 1 (fin = input 0).
+  // FULL: every channel group holds 128 channels (C % 128 == 0), so no MFMA needs a
+  // guard (a guard per MFMA costs three scalar instructions, 432 per window row).
   // VT: DMA width of the top segments.  For the gradient wrt input 0 they are
   // whole, aligned 64-byte segments.  Wrt input 1 they are shifted by the
   // displacement: 8-byte aligned, and a 16-byte piece may straddle the end of an
@@ -519,7 +521,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
           const float b = (dxok && b_rowok[sl]) ? bbuf[s4 & 1][sl] : 0.f;
 #pragma unroll
           for (int m = 0; m < MTS; ++m)
-            if (m < nmt) acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s4 & 1][m], b, acc[sl][m], 0, 0, 0);
+            if (FULL || m < nmt)
+              acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s4 & 1][m], b, acc[sl][m], 0, 0, 0);
         }
       }
       if (more) issue_slice(S4, w + 1, nxt);
@@ -633,17 +636,19 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
   const dim3 grid(nbx * nch * S * B);
   const size_t smem = sizeof(float) * SW_LDS;
   const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(topdiff);
-#define UNFLOW_LAUNCH(VA, VT0)                                                                                \
-  do {                                                                                                        \
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, false>, smem, "correlation_bwd (mfma)")) return rc; \
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, true>, smem, "correlation_bwd (mfma)")) return rc;    \
-    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, false>), grid, dim3(NTHREADS), smem, s, topdiff, in1, g0, C, H, \
-                       W, nbx, nch);                                                                          \
-    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, true>), grid, dim3(NTHREADS), smem, s, topdiff, in0, g1, C, H,    \
-                       W, nbx, nch);                                                                          \
+#define UNFLOW_LAUNCH(VA, VT0, FULL)                                                                               \
+  do {                                                                                                              \
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, false, FULL>, smem, "correlation_bwd (mfma)")) return rc; \
+    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, true, FULL>, smem, "correlation_bwd (mfma)")) return rc;  \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, false, FULL>), grid, dim3(NTHREADS), smem, s, topdiff, in1, g0, \
+                       C, H, W, nbx, nch);                                                                          \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, true, FULL>), grid, dim3(NTHREADS), smem, s, topdiff, in0, g1,  \
+                       C, H, W, nbx, nch);                                                                          \
   } while (0)
-  if (wide) UNFLOW_LAUNCH(4, 4);
-  else UNFLOW_LAUNCH(1, 1);
+  const bool full = (C % CWS) == 0;
+  if (wide && full) UNFLOW_LAUNCH(4, 4, true);
+  else if (wide) UNFLOW_LAUNCH(4, 4, false);
+  else UNFLOW_LAUNCH(1, 1, false);
 #undef UNFLOW_LAUNCH
   return launch_status("correlation_bwd (mfma)");
 }
