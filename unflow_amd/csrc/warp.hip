@@ -17,6 +17,11 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Makes a loaded value opaque to the optimiser (no instruction is emitted): a
+// load that feeds only a select would otherwise be turned back into a branch
+// around the load, one branch and one wait per tap.
+__device__ inline void pin(float &v) { asm volatile("" : "+v"(v)); }
+
 struct Taps {
   int x0, x1, y0, y1;
   float w_left, w_right, w_top, w_bottom;
@@ -67,15 +72,31 @@ __global__ __launch_bounds__(kBlock) void backward_warp_fwd_kernel(const float *
     const float w00 = t.w_left * t.w_top, w01 = t.w_right * t.w_top;
     const float w10 = t.w_left * t.w_bottom, w11 = t.w_right * t.w_bottom;
     float *out = output + idx * nc;
+    // selects, not branches: a tap outside the image contributes fmaf(w, 0, sum) == sum
+    // exactly; pin() keeps the compiler from sinking the loads back under a condition.
+    // For the unrolled channel counts all loads of the pixel are issued before the first use.
+    constexpr int NC = C > 0 ? C : 1;
+    for (int cb = 0; cb < nc; cb += NC) {
+      float l00[NC], l01[NC], l10[NC], l11[NC];
 #pragma unroll
-    for (int c = 0; c < nc; ++c) {
-      const float v00 = p00[c], v01 = p01[c], v10 = p10[c], v11 = p11[c];
-      float sum = 0.f;
-      if (in00) sum = fmaf(w00, v00, sum);
-      if (in01) sum = fmaf(w01, v01, sum);
-      if (in10) sum = fmaf(w10, v10, sum);
-      if (in11) sum = fmaf(w11, v11, sum);
-      out[c] = sum;
+      for (int c = 0; c < NC; ++c) {
+        l00[c] = p00[cb + c];
+        l01[c] = p01[cb + c];
+        l10[c] = p10[cb + c];
+        l11[c] = p11[cb + c];
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        pin(l00[c]); pin(l01[c]); pin(l10[c]); pin(l11[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float sum = fmaf(w00, in00 ? l00[c] : 0.f, 0.f);
+        sum = fmaf(w01, in01 ? l01[c] : 0.f, sum);
+        sum = fmaf(w10, in10 ? l10[c] : 0.f, sum);
+        sum = fmaf(w11, in11 ? l11[c] : 0.f, sum);
+        out[cb + c] = sum;
+      }
     }
   }
 }
@@ -106,29 +127,34 @@ __global__ __launch_bounds__(kBlock) void backward_warp_bwd_kernel(const float *
     const bool in00 = in_x0 && in_y0, in01 = in_x1 && in_y0, in10 = in_x0 && in_y1, in11 = in_x1 && in_y1;
     const float *gin = input_grad + idx * nc;
     float du = 0.f, dv = 0.f;
+    constexpr int NC = C > 0 ? C : 1;
+    for (int cb = 0; cb < nc; cb += NC) {
+      float l00[NC], l01[NC], l10[NC], l11[NC], din[NC];
 #pragma unroll
-    for (int c = 0; c < nc; ++c) {
-      const float din = gin[c];
-      const float v00 = p00[c], v01 = p01[c], v10 = p10[c], v11 = p11[c];
-      if (in00) {
-        const float px = v00 * din;
-        du = fmaf(-t.w_top, px, du);
-        dv = fmaf(-t.w_left, px, dv);
+      for (int c = 0; c < NC; ++c) {
+        l00[c] = p00[cb + c];
+        l01[c] = p01[cb + c];
+        l10[c] = p10[cb + c];
+        l11[c] = p11[cb + c];
+        din[c] = gin[cb + c];
       }
-      if (in01) {
-        const float px = v01 * din;
-        du = fmaf(t.w_top, px, du);
-        dv = fmaf(-t.w_right, px, dv);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        pin(l00[c]); pin(l01[c]); pin(l10[c]); pin(l11[c]);
       }
-      if (in10) {
-        const float px = v10 * din;
-        du = fmaf(-t.w_bottom, px, du);
-        dv = fmaf(t.w_left, px, dv);
-      }
-      if (in11) {
-        const float px = v11 * din;
-        du = fmaf(t.w_bottom, px, du);
-        dv = fmaf(t.w_right, px, dv);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        // masked products: an outside tap adds fmaf(w, 0, d) == d exactly
+        const float q00 = (in00 ? l00[c] : 0.f) * din[c], q01 = (in01 ? l01[c] : 0.f) * din[c];
+        const float q10 = (in10 ? l10[c] : 0.f) * din[c], q11 = (in11 ? l11[c] : 0.f) * din[c];
+        du = fmaf(-t.w_top, q00, du);
+        dv = fmaf(-t.w_left, q00, dv);
+        du = fmaf(t.w_top, q01, du);
+        dv = fmaf(-t.w_right, q01, dv);
+        du = fmaf(-t.w_bottom, q10, du);
+        dv = fmaf(t.w_left, q10, dv);
+        du = fmaf(t.w_bottom, q11, du);
+        dv = fmaf(t.w_right, q11, dv);
       }
     }
     output_grad[idx] = make_float2(du, dv);
@@ -181,18 +207,29 @@ __global__ __launch_bounds__(kBlock) void image_warp_fwd_kernel(const float *__r
     const float wc = t.xw * (1.f - t.yw);
     const float wd = t.xw * t.yw;
     float *out = warped + idx * nc;
+    constexpr int NC = C > 0 ? C : 1;
+    for (int cb = 0; cb < nc; cb += NC) {
+      float la[NC], lb[NC], lc[NC], ld[NC];   // all taps of the pixel in flight before the first use
 #pragma unroll
-    for (int c = 0; c < nc; ++c) {
-      float s = __fmul_rn(wa, pa[c]);
-      s = __fadd_rn(s, __fmul_rn(wb, pb[c]));
-      s = __fadd_rn(s, __fmul_rn(wc, pc[c]));
-      s = __fadd_rn(s, __fmul_rn(wd, pd[c]));
-      out[c] = s;
+      for (int c = 0; c < NC; ++c) {
+        la[c] = pa[cb + c];
+        lb[c] = pb[cb + c];
+        lc[c] = pc[cb + c];
+        ld[c] = pd[cb + c];
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float s = __fmul_rn(wa, la[c]);
+        s = __fadd_rn(s, __fmul_rn(wb, lb[c]));
+        s = __fadd_rn(s, __fmul_rn(wc, lc[c]));
+        s = __fadd_rn(s, __fmul_rn(wd, ld[c]));
+        out[cb + c] = s;
+      }
     }
   }
 }
 
-template <int C>
+template <int C, bool WANT_IM, bool WANT_FLOW>
 __global__ __launch_bounds__(kBlock) void image_warp_bwd_kernel(const float *__restrict__ grad,
                                                                 const float *__restrict__ im,
                                                                 const float2 *__restrict__ flow,
@@ -200,6 +237,7 @@ __global__ __launch_bounds__(kBlock) void image_warp_bwd_kernel(const float *__r
                                                                 float2 *__restrict__ d_flow, int H, int W,
                                                                 int channels, long long total) {
   const int nc = C > 0 ? C : channels;
+  constexpr int NC = C > 0 ? C : 1;
   for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * kBlock) {
     const int pos_x = (int)(idx % W);
@@ -213,25 +251,39 @@ __global__ __launch_bounds__(kBlock) void image_warp_bwd_kernel(const float *__r
     const float wc = t.xw * (1.f - t.yw);
     const float wd = t.xw * t.yw;
     const float *g = grad + idx * nc;
+    const float *pa = im + item + t.ia * nc, *pb = im + item + t.ib * nc;
+    const float *pc = im + item + t.ic * nc, *pd = im + item + t.id * nc;
     float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
+    for (int cb = 0; cb < nc; cb += NC) {
+      float gv[NC], la[NC], lb[NC], lc[NC], ld[NC];
 #pragma unroll
-    for (int c = 0; c < nc; ++c) {
-      const float gv = g[c];
-      if (d_im) {
-        // gradient of tf.gather: scatter-add at the clamped taps
-        unsafeAtomicAdd(d_im + item + t.ia * nc + c, wa * gv);
-        unsafeAtomicAdd(d_im + item + t.ib * nc + c, wb * gv);
-        unsafeAtomicAdd(d_im + item + t.ic * nc + c, wc * gv);
-        unsafeAtomicAdd(d_im + item + t.id * nc + c, wd * gv);
+      for (int c = 0; c < NC; ++c) {
+        gv[c] = g[cb + c];
+        if (WANT_FLOW) {
+          la[c] = pa[cb + c];
+          lb[c] = pb[cb + c];
+          lc[c] = pc[cb + c];
+          ld[c] = pd[cb + c];
+        }
       }
-      if (d_flow) {
-        ga = fmaf(gv, im[item + t.ia * nc + c], ga);
-        gb = fmaf(gv, im[item + t.ib * nc + c], gb);
-        gc = fmaf(gv, im[item + t.ic * nc + c], gc);
-        gd = fmaf(gv, im[item + t.id * nc + c], gd);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (WANT_IM) {
+          // gradient of tf.gather: scatter-add at the clamped taps
+          unsafeAtomicAdd(d_im + item + t.ia * nc + cb + c, wa * gv[c]);
+          unsafeAtomicAdd(d_im + item + t.ib * nc + cb + c, wb * gv[c]);
+          unsafeAtomicAdd(d_im + item + t.ic * nc + cb + c, wc * gv[c]);
+          unsafeAtomicAdd(d_im + item + t.id * nc + cb + c, wd * gv[c]);
+        }
+        if (WANT_FLOW) {
+          ga = fmaf(gv[c], la[c], ga);
+          gb = fmaf(gv[c], lb[c], gb);
+          gc = fmaf(gv[c], lc[c], gc);
+          gd = fmaf(gv[c], ld[c], gd);
+        }
       }
     }
-    if (d_flow) {
+    if (WANT_FLOW) {
       const float dxw = (gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw;
       const float dyw = (gb - ga) * (1.f - t.xw) + (gd - gc) * t.xw;
       d_flow[idx] = make_float2(dxw, dyw);
@@ -477,8 +529,21 @@ extern "C" int unflow_image_warp_bwd(const float *grad, const float *im, const f
       return launch_status("image_warp_bwd memset");
   }
   const unsigned grid = grid_for(total);
-  DISPATCH_C(image_warp_bwd_kernel, C, grad, im, reinterpret_cast<const float2 *>(flow), d_im,
-             reinterpret_cast<float2 *>(d_flow), H, W, C, total);
+#define IW_BWD(C_, IM_, FL_)                                                                              \
+  hipLaunchKernelGGL((image_warp_bwd_kernel<C_, IM_, FL_>), dim3(grid), dim3(kBlock), 0, s, grad, im,     \
+                     reinterpret_cast<const float2 *>(flow), d_im, reinterpret_cast<float2 *>(d_flow), H, W, C, total)
+#define IW_BWD_C(IM_, FL_)                   \
+  switch (C) {                               \
+    case 1: IW_BWD(1, IM_, FL_); break;      \
+    case 2: IW_BWD(2, IM_, FL_); break;      \
+    case 3: IW_BWD(3, IM_, FL_); break;      \
+    default: IW_BWD(0, IM_, FL_);            \
+  }
+  if (d_im && d_flow) { IW_BWD_C(true, true) }
+  else if (d_im) { IW_BWD_C(true, false) }
+  else { IW_BWD_C(false, true) }
+#undef IW_BWD_C
+#undef IW_BWD
   return launch_status("image_warp_bwd");
 }
 
