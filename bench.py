@@ -192,6 +192,25 @@ def main():
     if rank == 0:
         pairs = args.batch * world * args.steps
         achieved_tf = CORR_BWD_FLOP * args.batch / (bwd_ms * 1e-3) / 1e12
+        # HBM bytes of that launch from PMC counters are collected offline (bench.py cannot
+        # run under rocprofv3 --pmc and time itself): tools/traffic_pmc.sh -> profiles/r01_traffic.json
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and args.batch == 32:
+            with open(tpath) as fh:
+                traffic = json.load(fh)["corr_bwd_both_launches"]["hbm_bytes"]
+        # measured copy roofline of this GPU (1 GiB device-to-device)
+        a = torch.empty(256 * 1024 * 1024, device=dev)
+        b = torch.empty_like(a)
+        b.copy_(a)
+        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(3):
+            b.copy_(a)
+        e0.record()
+        torch.cuda.synchronize()
+        copy_gbs = 3 * 2 * a.numel() * 4 / (s0.elapsed_time(e0) * 1e-3) / 1e9
+        del a, b
         out = {
             "metric": "image-pairs/sec (corr+warp+census fwd+bwd) at 384x1280 b32",
             "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -202,9 +221,11 @@ def main():
                                    "2 ternary 7x7) fwd+bwd" % args.batch,
                        "global_batch": args.batch * world, "height": H, "width": W,
                        "parallelism": "batch-sharded x%d, all-reduce of loss + 156.7 MB grad buffer" % world},
-            "roofline": {"bound": "mfma", "kernel": "correlation backward (corr_mfma_bwd)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "correlation backward: corr_mfma_bwd_kernel, both gradient launches of one call",
                          "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP32_MATRIX_PEAK_TF, "traffic": None,
+                         "frac": achieved_tf / FP32_MATRIX_PEAK_TF, "traffic": traffic,
+                         "measured_copy_gbs": copy_gbs,
                          "avg_launch_ms": bwd_ms,
                          "hbm_gbs": CORR_BWD_BYTES * args.batch / (bwd_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBs": CORR_BWD_BYTES * args.batch / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

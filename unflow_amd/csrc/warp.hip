@@ -409,6 +409,7 @@ __global__ __launch_bounds__(kBlock) void forward_warp_bwd_kernel(const float *_
                                                                   const float2 *__restrict__ flows,
                                                                   float2 *__restrict__ output_grad, int H,
                                                                   int W, long long total) {
+  // du = sum_n 2*din[n]*w(n)*(n_x - t_x)/2,  w separable: 9 + 9 exponentials per pixel
   for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * kBlock) {
     const int src_x = (int)(idx % W);
@@ -419,17 +420,28 @@ __global__ __launch_bounds__(kBlock) void forward_warp_bwd_kernel(const float *_
     float du = 0.f, dv = 0.f;
     if (w.any) {
       const float *gin = input_grad + b * H * W;
-      for (int n_x = w.min_x; n_x <= w.max_x; ++n_x) {
-        const float x = (float)n_x - w.tx;
-        const float xx = x * x;
-        for (int n_y = w.min_y; n_y <= w.max_y; ++n_y) {
-          const float y = (float)n_y - w.ty;
-          const float weight = expf(-(xx + y * y) / 2.f);
-          const float din = gin[(long long)n_y * W + n_x];
-          const float factor = 2.f * din * weight / 2.f;
-          du = fmaf(factor, x, du);
-          dv = fmaf(factor, y, dv);
+      float ex[9], dx[9];
+#pragma unroll
+      for (int a = 0; a < 9; ++a) {
+        dx[a] = (float)(w.min_x + a) - w.tx;
+        ex[a] = gauss(dx[a]);
+      }
+      const int nx = w.max_x - w.min_x;
+      for (int n_y = w.min_y; n_y <= w.max_y; ++n_y) {
+        const float y = (float)n_y - w.ty;
+        const float ey = gauss(y);
+        const float *grow = gin + (long long)n_y * W + w.min_x;
+        float sx = 0.f, s0 = 0.f;              // sum_x din*ex*x and sum_x din*ex of this row
+#pragma unroll
+        for (int a = 0; a < 9; ++a) {
+          if (a <= nx) {
+            const float f = grow[a] * ex[a];
+            sx = fmaf(f, dx[a], sx);
+            s0 += f;
+          }
         }
+        du = fmaf(ey, sx, du);
+        dv = fmaf(ey * y, s0, dv);
       }
     }
     output_grad[idx] = make_float2(du, dv);
