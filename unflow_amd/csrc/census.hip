@@ -81,6 +81,7 @@ __global__ __launch_bounds__(kNT) void ternary_fwd_kernel(const float *__restric
         const float e = df * df;
         dist_sum = fmaf(e, __builtin_amdgcn_rcpf(0.1f + e), dist_sum);
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of one window row together (register pressure)
     }
     const long long p = item_px + (long long)y * W + x;
     if (dist_out) dist_out[p] = dist_sum;
@@ -126,7 +127,9 @@ __global__ __launch_bounds__(kNT) void ternary_bwd_kernel(const float *__restric
   const int cidx = (ty + r) * lw + tx + r;
   const float c1 = g1[cidx], c2 = g2[cidx], cd = gd[cidx];
   float acc = 0.f;
-#pragma unroll
+  // The row loop is kept rolled: fully unrolled, all 147 LDS reads of the window
+  // are hoisted to the top (157 VGPRs, 3 waves per SIMD instead of 8).
+#pragma unroll 1
   for (int i = 0; i < 2 * r + 1; ++i) {
 #pragma unroll
     for (int j = 0; j < 2 * r + 1; ++j) {
@@ -139,7 +142,8 @@ __global__ __launch_bounds__(kNT) void ternary_bwd_kernel(const float *__restric
       const float df = d1 * r1 - d2 * r2;
       const float inv = __builtin_amdgcn_rcpf(fmaf(df, df, 0.1f));
       // G = -0.2*df*inv^2 * 0.81*r2^3 ; acc -= w*G
-      acc = fmaf(w * df, (inv * inv) * (r2 * r2 * r2), acc);
+      const float q = inv * r2;
+      acc = fmaf(w * df, (q * q) * r2, acc);
     }
   }
   const float go = gout ? *gout : 1.f;
