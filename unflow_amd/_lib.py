@@ -59,6 +59,9 @@ def load():
             raise UnflowLibraryError(
                 "libunflow_hip.so not found at %s -- build it with `make -C unflow_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback" % LIB_PATH)
+        # torch first: it ships its own libamdhip64.so.7, and the HIP runtime that is loaded
+        # first serves the whole process -- the tensors (torch) and these kernels must share it
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported

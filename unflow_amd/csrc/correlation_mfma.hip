@@ -586,13 +586,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-template <typename K>
-int reserve_lds(K kernel, size_t smem, const char *what) {
-  // > 64 KiB of dynamic LDS needs an opt-in: once per kernel (thread-safe static; smem is a constant of K)
-  static const hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+// > 64 KiB of dynamic LDS needs an opt-in, once per kernel.  The kernel is a
+// template VALUE parameter: all instantiations of one kernel template share a
+// function type, and a static keyed on the type would be set for the first only.
+template <auto KERNEL>
+int reserve_lds(size_t smem, const char *what) {
+  static const hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  if (st != hipSuccess)
-    return fail(UNFLOW_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS", what, smem);
+  if (st != hipSuccess) return fail(UNFLOW_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS (%s)", what, smem, hipGetErrorString(st));
   return UNFLOW_OK;
 }
 
@@ -618,10 +619,10 @@ int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, 
   // 16-byte DMA segments need 16-byte aligned rows
   const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1);
   if (wide) {
-    if (int rc = reserve_lds(corr_mfma_fwd_kernel<4>, smem, "correlation_fwd (mfma)")) return rc;
+    if (int rc = reserve_lds<corr_mfma_fwd_kernel<4>>(smem, "correlation_fwd (mfma)")) return rc;
     hipLaunchKernelGGL(corr_mfma_fwd_kernel<4>, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby);
   } else {
-    if (int rc = reserve_lds(corr_mfma_fwd_kernel<1>, smem, "correlation_fwd (mfma)")) return rc;
+    if (int rc = reserve_lds<corr_mfma_fwd_kernel<1>>(smem, "correlation_fwd (mfma)")) return rc;
     hipLaunchKernelGGL(corr_mfma_fwd_kernel<1>, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby);
   }
   return launch_status("correlation_fwd (mfma)");
@@ -638,8 +639,8 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
   const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(topdiff);
 #define UNFLOW_LAUNCH(VA, VT0, FULL)                                                                               \
   do {                                                                                                              \
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, false, FULL>, smem, "correlation_bwd (mfma)")) return rc; \
-    if (int rc = reserve_lds(corr_mfma_bwd_kernel<VA, VT0, true, FULL>, smem, "correlation_bwd (mfma)")) return rc;  \
+    if (int rc = reserve_lds<corr_mfma_bwd_kernel<VA, VT0, false, FULL>>(smem, "correlation_bwd (mfma)")) return rc; \
+    if (int rc = reserve_lds<corr_mfma_bwd_kernel<VA, VT0, true, FULL>>(smem, "correlation_bwd (mfma)")) return rc;  \
     hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, false, FULL>), grid, dim3(NTHREADS), smem, s, topdiff, in1, g0, \
                        C, H, W, nbx, nch);                                                                          \
     hipLaunchKernelGGL((corr_mfma_bwd_kernel<VA, VT0, true, FULL>), grid, dim3(NTHREADS), smem, s, topdiff, in0, g1,  \

@@ -427,18 +427,24 @@ __global__ __launch_bounds__(kBlock) void forward_warp_bwd_kernel(const float *_
         ex[a] = gauss(dx[a]);
       }
       const int nx = w.max_x - w.min_x;
+#pragma unroll 1
       for (int n_y = w.min_y; n_y <= w.max_y; ++n_y) {
         const float y = (float)n_y - w.ty;
         const float ey = gauss(y);
         const float *grow = gin + (long long)n_y * W + w.min_x;
+        // clamped, unconditional loads (a guarded load is a branch and a wait per tap);
+        // taps beyond the window are masked afterwards
+        float gv[9];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) gv[a] = grow[min(a, nx)];
+#pragma unroll
+        for (int a = 0; a < 9; ++a) pin(gv[a]);
         float sx = 0.f, s0 = 0.f;              // sum_x din*ex*x and sum_x din*ex of this row
 #pragma unroll
         for (int a = 0; a < 9; ++a) {
-          if (a <= nx) {
-            const float f = grow[a] * ex[a];
-            sx = fmaf(f, dx[a], sx);
-            s0 += f;
-          }
+          const float f = a <= nx ? gv[a] * ex[a] : 0.f;
+          sx = fmaf(f, dx[a], sx);
+          s0 += f;
         }
         du = fmaf(ey, sx, du);
         dv = fmaf(ey * y, s0, dv);
