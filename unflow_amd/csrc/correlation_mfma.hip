@@ -79,61 +79,63 @@ __device__ inline int xcd_remap(int b, int nblk) { return (nblk & 7) == 0 ? (b &
 // ===========================================================================
 // Forward
 // ===========================================================================
-constexpr int KC = 8;                        // channels per LDS stage
+constexpr int KC = 8;                        // channels per LDS stage (= waves: wave w stages channel w)
+static_assert(KC == NWAVES, "each wave stages one channel plane of the chunk");
 constexpr int PLANE = LH * ROWF;             // 1568 floats: [row 28][x 56] of one channel
+constexpr int PLS = PLANE + 4;               // plane stride; odd planes start ONE FLOAT later (see below)
 constexpr int F0PL = RY * RW;                // 128 floats:  [row 8][x 16]
-constexpr int F1_STAGE = KC * PLANE;         // 12544
+constexpr int F1_STAGE = (KC * PLS + 1 + 63) / 64 * 64;   // 12608
 constexpr int F0_STAGE = KC * F0PL;          // 1024
-constexpr int STAGE = F1_STAGE + F0_STAGE;   // 13568 floats = 53 KB
+constexpr int STAGE = F1_STAGE + F0_STAGE;   // 13632 floats = 53 KB
 constexpr int SLAB_DY = 7;                   // displacement rows per epilogue slab
 constexpr int SLAB = SLAB_DY * GW * RY * RW; // floats
 static_assert(SLAB <= 2 * STAGE, "epilogue slab must fit the staging buffers");
 static_assert(GW % SLAB_DY == 0, "slabs must tile the displacement rows");
 // B fragment (ds_read_b32; per 32-lane half: 2 channels x 4 rows x 4 columns of
 // one class): rows land on distinct multiples of 8 (56 = 24 mod 32), columns on
-// 2*col, so the 16 positions take the 16 banks of one parity; the half's second
-// channel takes the same banks: 2-way, the best a 16-byte aligned image allows.
-static_assert(ROWF % 32 == 24, "row stride must spread the 4 rows of a fragment");
+// 2*col, so the 16 positions of ONE channel take the 16 banks of one parity.
+// The half's second channel must therefore sit at an odd offset: the image of an
+// odd channel starts one float later (plane offset c*1572 + (c&1), 1573 = 5 mod
+// 32), which makes the read conflict free.  16-byte LDS-DMA into a destination
+// that is only 4-byte aligned works (tools/ubench/lds_dma_unaligned.hip).
+static_assert(ROWF % 32 == 24 && (PLS + 1) % 2 == 1, "LDS image would bank-conflict");
 
 template <int VEC>
 struct FwdStager {
+  // wave w stages plane w of f1 (1568 floats) piece by piece, and a share of the f0 image
   static constexpr int PIECE = 64 * VEC;
-  static_assert(F1_STAGE % PIECE == 0 && F0_STAGE % PIECE == 0, "stage must split into wave pieces");
-  static constexpr int F1_PIECES = F1_STAGE / PIECE;
-  static constexpr int PIECES = STAGE / PIECE;
-  static constexpr int PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;
+  static constexpr int F1_PER_WAVE = (PLANE + PIECE - 1) / PIECE;        // 7 (dwordx4) or 25 (dword); last one partial
+  static_assert(F0_STAGE % PIECE == 0, "f0 image must split into wave pieces");
+  static constexpr int F0_PIECES = F0_STAGE / PIECE;                     // 4 or 16
+  static constexpr int F0_PER_WAVE = (F0_PIECES + NWAVES - 1) / NWAVES;  // 1 or 2
+  static constexpr int PER_WAVE = F1_PER_WAVE + F0_PER_WAVE;
 
   unsigned voff[PER_WAVE];
   int wave;
   __amdgpu_buffer_rsrc_t r0, r1;
 
-  // byte offset (relative to channel c0 of the item) of stage float `f`, or OOB
-  static __device__ inline unsigned offset_of(int f, int H, int W, int cy, int ys0, int xs0) {
-    int c, Y, X;
-    if (f < F1_STAGE) {
-      c = f / PLANE;
-      const int r = f - c * PLANE, row = r / ROWF, x = r - row * ROWF;
-      Y = S * (ys0 - R + row) + cy;
-      X = S * (xs0 - R) + x;
-    } else {
-      const int g = f - F1_STAGE;
-      c = g / F0PL;
-      const int r = g - c * F0PL, row = r / RW, x = r - row * RW;
-      Y = S * (ys0 + row) + cy;
-      X = S * xs0 + x;
-    }
-    // VEC > 1: X and W are multiples of VEC, so a segment is inside or outside as a whole
-    const bool in = Y >= 0 && Y < H && X >= 0 && X < W;
-    return in ? (unsigned)(((long long)c * H * W + (long long)Y * W + X) * 4) : OOB;
-  }
   __device__ inline void init(int H, int W, int cy, int ys0, int xs0) {
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __builtin_assume(wave >= 0 && wave < NWAVES);
     const int lane = threadIdx.x & 63;
+    const long long plane = (long long)H * W;
+    // VEC > 1: X and W are multiples of VEC, so a segment is inside or outside as a whole
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) {
+    for (int j = 0; j < F1_PER_WAVE; ++j) {
+      const int f = (j * 64 + lane) * VEC;               // float inside the plane
+      const int row = f / ROWF, x = f - row * ROWF;
+      const int Y = S * (ys0 - R + row) + cy, X = S * (xs0 - R) + x;
+      const bool in = f < PLANE && Y >= 0 && Y < H && X >= 0 && X < W;
+      voff[j] = in ? (unsigned)((wave * plane + (long long)Y * W + X) * 4) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < F0_PER_WAVE; ++j) {
       const int p = wave + NWAVES * j;
-      voff[j] = p < PIECES ? offset_of((p * 64 + lane) * VEC, H, W, cy, ys0, xs0) : OOB;
+      const int f = (p * 64 + lane) * VEC;               // float inside the f0 image [c][row][x]
+      const int c = f / F0PL, r = f - c * F0PL, row = r / RW, x = r - row * RW;
+      const int Y = S * (ys0 + row) + cy, X = S * xs0 + x;
+      const bool in = p < F0_PIECES && Y >= 0 && Y < H && X >= 0 && X < W;
+      voff[F1_PER_WAVE + j] = in ? (unsigned)((c * plane + (long long)Y * W + X) * 4) : OOB;
     }
   }
   __device__ inline void bind(const float *in0, const float *in1, long long item, int c0, int C, long long plane) {
@@ -143,11 +145,18 @@ struct FwdStager {
   }
   template <int J>
   __device__ inline void issue_one(float *stage) const {
-    if constexpr (J < PER_WAVE) {
+    if constexpr (J < F1_PER_WAVE) {
       __builtin_assume(wave >= 0 && wave < NWAVES);
-      const int p = wave + NWAVES * J;
-      if (p < F1_PIECES) dma<VEC>(r1, stage + p * PIECE, voff[J], 0);
-      else if (p < PIECES) dma<VEC>(r0, stage + p * PIECE, voff[J], 0);
+      float *dst = stage + wave * PLS + (wave & 1) + J * PIECE;
+      if constexpr ((J + 1) * PIECE <= PLANE) {
+        dma<VEC>(r1, dst, voff[J], 0);
+      } else {                                             // partial last piece: only the lanes inside the plane
+        if ((int)((J * 64 + (threadIdx.x & 63)) * VEC) < PLANE) dma<VEC>(r1, dst, voff[J], 0);
+      }
+    } else if constexpr (J < PER_WAVE) {
+      __builtin_assume(wave >= 0 && wave < NWAVES);
+      const int p = wave + NWAVES * (J - F1_PER_WAVE);
+      if (p < F0_PIECES) dma<VEC>(r0, stage + F1_STAGE + p * PIECE, voff[J], 0);
     }
   }
   template <int J0, int N>
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   // per-lane fragment addresses inside one stage (floats)
   const int k = lane >> 4, n = lane & 15;
   const int a_off = F1_STAGE + k * F0PL + (ty * TP + (n >> 2)) * RW + S * (tx * TP + (n & 3)) + cx;
-  const int b_off = k * PLANE + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + cx;
+  const int b_off = k * PLS + (k & 1) + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + cx;
 
   // N-tiles (4x4 blocks of window positions) that lie entirely in the zero
   // padding have an all-zero B operand: their MFMAs are skipped (wave-uniform
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
       // all fragment reads of the K-step are issued first; the MFMAs then wait
       // with a decreasing lgkmcnt, so one LDS latency is exposed per 36 MFMAs
       const float a = cur[a_off + kk * 4 * F0PL];
-      const float *bp = cur + b_off + kk * 4 * PLANE;
+      const float *bp = cur + b_off + kk * 4 * PLS;
       float b[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) b[t] = bp[(t / TQ) * 4 * ROWF + (t % TQ) * 4 * S];
