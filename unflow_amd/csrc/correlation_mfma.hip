@@ -90,7 +90,7 @@ constexpr int STAGE = F1_STAGE + F0_STAGE;   // 13632 floats = 53 KB
 constexpr int SLAB_DY = 7;                   // displacement rows per epilogue slab
 constexpr int SLAB = SLAB_DY * GW * RY * RW; // floats
 static_assert(SLAB <= 2 * STAGE, "epilogue slab must fit the staging buffers");
-static_assert(GW % SLAB_DY == 0, "slabs must tile the displacement rows");
+static_assert(GW % SLAB_DY == 0 && GW / SLAB_DY == 3, "three slabs tile the displacement rows");
 // B fragment (ds_read_b32; per 32-lane half: 2 channels x 4 rows x 4 columns of
 // one class): rows land on distinct multiples of 8 (56 = 24 mod 32), columns on
 // 2*col, so the 16 positions of ONE channel take the 16 banks of one parity.
@@ -194,19 +194,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   const int a_off = F1_STAGE + k * F0PL + (ty * TP + (n >> 2)) * RW + S * (tx * TP + (n & 3)) + cx;
   const int b_off = k * PLS + (k & 1) + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + cx;
 
-  // N-tiles (4x4 blocks of window positions) that lie entirely in the zero
-  // padding have an all-zero B operand: their MFMAs are skipped (wave-uniform
-  // masks).  At 48x160 that is 21 % of the tiles.
-  unsigned rowmask = 0, colmask = 0;
+  // Rows of N-tiles (4 window rows) that lie entirely in the zero padding above
+  // or below the image have an all-zero B operand: their MFMAs are skipped
+  // (wave-uniform mask).  At 48x160 that is 17 % of the tiles.
+  unsigned rowmask = 0;
   {
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int tyu = (wv >> 1) & 1, txu = wv >> 2, cxu = wv & 1;
-    const int wsu = (W - cxu + S - 1) / S;     // class columns that exist for this wave's cx
+    const int tyu = (wv >> 1) & 1;
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
-      const int r0 = ys0 + tyu * TP - R + 4 * q, c0q = xs0 + txu * TP - R + 4 * q;
+      const int r0 = ys0 + tyu * TP - R + 4 * q;
       if (r0 + 3 >= 0 && r0 < hs) rowmask |= 1u << q;
-      if (c0q + 3 >= 0 && c0q < wsu) colmask |= 1u << q;
     }
   }
 
@@ -238,11 +236,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
       __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs
       auto group = [&](auto G) {
         constexpr int g = decltype(G)::value;
+        // one branch per row of 6 N-tiles, not one per MFMA: a taken branch after
+        // every MFMA starves the matrix pipe (45 % busy with per-tile column masks)
         if (rowmask & (1u << g)) {
 #pragma unroll
           for (int t = g * TQ; t < (g + 1) * TQ; ++t)
-            if (colmask & (1u << (t - g * TQ)))
-              acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
         }
         if (more) {
           if (kk == 0) st.template issue_range<g * PER_GROUP, PER_GROUP>(nxt);
@@ -261,30 +260,61 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   // Slab image [row][col][dy][dx]: with the displacement innermost the 64 lanes
   // of one scatter instruction (which differ in dy, dx and row) spread over the
   // banks (<= 2-way); a [dy][dx][row][col] image would put them all on 2 banks.
+  // Everything that depends on the lane is computed once: with u = (n>>2) - py and
+  // bq = n&3 an element (t, j) has dy' = 4*tqy + u and dx' = 4*tqx + bq - j, so its
+  // slab address is L[j] + a compile-time constant, its dy' test is a range test on
+  // u per (slab, tqy), and its dx' test only exists for the first and last tile
+  // column.  (Per-element index arithmetic and an inline float division made this
+  // epilogue cost a third of the kernel.)
   const float scale = 1.f / (float)C;
   const bool pow2 = (C & (C - 1)) == 0;
   const int py = lane >> 4;
   const int row = ty * TP + py;                       // class row inside the region
   const int D = GW * GW;
   float *ob = lds;
+  const int u = (n >> 2) - py, bq = n & 3;
+  int L[4];
+  bool mx_first[4], mx_last[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    L[j] = (row * RW + S * (tx * TP + j) + cx) * (SLAB_DY * GW) + u * GW + (bq - j);
+    mx_first[j] = bq >= j;       // tqx == 0     : dx' = bq - j >= 0
+    mx_last[j] = bq <= j;        // tqx == TQ - 1: dx' = 4*(TQ-1) + bq - j <= 2R
+  }
+  static_assert(4 * (TQ - 1) == 2 * R, "last tile column starts at dx' = 2R");
+  auto scatter = [&](auto SLABNO, auto DIVIDE) {
+    constexpr int s = decltype(SLABNO)::value;
+    constexpr bool divide = decltype(DIVIDE)::value;
+#pragma unroll
+    for (int tqy = 0; tqy < TQ; ++tqy) {
+      // dy' = 4*tqy + u must lie in [7s, min(7s+6, 2R)], u in [-3, 3]
+      constexpr int dlo = s * SLAB_DY, dhi = (s * SLAB_DY + SLAB_DY - 1) < 2 * R ? (s * SLAB_DY + SLAB_DY - 1) : 2 * R;
+      const int lo = dlo - 4 * tqy, hi = dhi - 4 * tqy;
+      if (hi < -3 || lo > 3) continue;          // compile-time: this tile row cannot hit the slab
+      const bool my = u >= lo && u <= hi;
+#pragma unroll
+      for (int tqx = 0; tqx < TQ; ++tqx) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = my && (tqx == 0 ? mx_first[j] : (tqx == TQ - 1 ? mx_last[j] : true));
+          if (ok) {
+            const float v = acc[tqy * TQ + tqx][j];
+            ob[L[j] + (4 * tqy - s * SLAB_DY) * GW + 4 * tqx] = divide ? v / (float)C : v * scale;
+          }
+        }
+      }
+    }
+  };
 #pragma unroll
   for (int s = 0; s < GW / SLAB_DY; ++s) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int tqy = t / TQ, tqx = t % TQ;
-      // dd = 4*tqy + (n>>2) - py lies in [4*tqy-3, 4*tqy+3]; skip tiles that cannot hit the slab
-      if (4 * tqy + 3 < s * SLAB_DY || 4 * tqy - 3 >= (s + 1) * SLAB_DY) continue;
-      const int dd = 4 * tqy + (n >> 2) - py;
-      const int ddl = dd - s * SLAB_DY;
-      if (ddl < 0 || ddl >= SLAB_DY || dd > 2 * R) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int dxx = 4 * tqx + (n & 3) - j;
-        if (dxx < 0 || dxx > 2 * R) continue;
-        const int col = S * (tx * TP + j) + cx;
-        const float v = acc[t][j];
-        ob[(row * RW + col) * (SLAB_DY * GW) + ddl * GW + dxx] = pow2 ? v * scale : v / (float)C;
-      }
+    if (pow2) {
+      if (s == 0) scatter(Int<0>{}, std::false_type{});
+      else if (s == 1) scatter(Int<1>{}, std::false_type{});
+      else scatter(Int<2>{}, std::false_type{});
+    } else {
+      if (s == 0) scatter(Int<0>{}, std::true_type{});
+      else if (s == 1) scatter(Int<1>{}, std::true_type{});
+      else scatter(Int<2>{}, std::true_type{});
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < SLAB / 4; idx += NTHREADS) {
@@ -548,9 +578,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
       const int fin_row = min(hs - 1, 4 * t + TP - 1 + R);
       if (fin_row != w) continue;                  // uniform over the workgroup
       float *ob = lds + 2 * SW_STAGE;
+      const float inv = 1.f / (float)C;
+      const bool pow2 = (C & (C - 1)) == 0;
       if ((t & 1) == ph) {
-        const float inv = 1.f / (float)C;
-        const bool pow2 = (C & (C - 1)) == 0;
         const int slot = (t >> 1) % RING;
 #pragma unroll
         for (int sl = 0; sl < RING; ++sl) {
@@ -561,7 +591,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
               for (int j = 0; j < 4; ++j) {
                 const int cl = m * 16 + 4 * k + j;
                 const float v = acc[sl][m][j];
-                ob[(cl * TP + oyl) * RW + b_col] = pow2 ? v * inv : v / (float)C;
+                ob[(cl * TP + oyl) * RW + b_col] = v;      // scaled by 1/C when the image is stored
                 acc[sl][m][j] = 0.f;
               }
             }
@@ -577,7 +607,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
         const int oy = 4 * t + rr;
         const int y = S * oy + cy, x = S * xs0 + c4 * 4;
         if (c >= C || oy >= hs || x >= W) continue;
-        const float4 v = *reinterpret_cast<const float4 *>(ob + idx * 4);
+        float4 v = *reinterpret_cast<const float4 *>(ob + idx * 4);
+        if (pow2) {
+          v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        } else {
+          v.x /= (float)C; v.y /= (float)C; v.z /= (float)C; v.w /= (float)C;
+        }
         float *dst = gout + (item * C + c) * plane + (long long)y * W + x;
         if (x + 3 < W && (W & 3) == 0) {
           *reinterpret_cast<float4 *>(dst) = v;
