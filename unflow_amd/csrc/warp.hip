@@ -313,83 +313,119 @@ __device__ inline Window splat_window(int src_x, int src_y, float2 f, int H, int
 }
 
 // Splat, LDS-privatised.  One workgroup owns a 64x16 tile of SOURCE pixels and
-// an LDS accumulation window of 96x48 output pixels centred on where the tile's
-// centre pixel lands.  Taps inside the window (coherent flow: almost all of
-// them) are accumulated in LDS; the rest fall back to global float atomics.  The
+// an LDS accumulation window of output pixels sized and placed to the bounding
+// box of everything the tile's pixels touch (up to 15360 cells = 60 KB: 96x48 for
+// a coherent flow, 133x85 for i.i.d. +-30 px flows).  Taps inside the window are
+// accumulated in LDS; if the box does not fit, the window is centred on where the
+// tile-centre pixel lands and the rest falls back to global float atomics.  The
 // window is then flushed with one global atomic per touched output pixel, in
-// 256-byte rows -- about 4.5 global atomics per source pixel instead of 81.
+// contiguous rows -- 3 to 11 global atomics per source pixel instead of 81.
 //
-// The LDS accumulator is 32-bit FIXED POINT (2^-22 per unit): on gfx950
-// ds_add_f32 retires about one lane per 3 cycles (194 cycles per wave
-// instruction, measured) while ds_add_u32 takes 5 cycles per wave instruction.
-// A tile has 1024 source pixels and a weight is at most 1, so with the scale
-// 2^21 a cell holds at most 1024 * 2^21 = 2^31 and cannot overflow.  The granule
-// 2^-21 ~ 4.8e-7 equals the float32 ulp at the typical density (2*pi), and
-// integer adds make the in-window sum independent of the order of the adds.
+// The LDS accumulator is 32-bit FIXED POINT: on gfx950 ds_add_f32 retires about
+// one lane per 3 cycles (194 cycles per wave instruction, measured) while
+// ds_add_u32 takes 5 cycles per wave instruction.  A tile has 1024 source pixels
+// and a weight is at most 1, so with the scale 2^21 a cell holds at most
+// 1024 * 2^21 = 2^31 and cannot overflow.  The granule 2^-21 ~ 4.8e-7 equals
+// the float32 ulp at the typical density (2*pi), and integer adds make the
+// in-window sum independent of the order of the adds.
 // The Gaussian is separable: 9 + 9 instead of 81 exponentials per pixel.
 constexpr int kSX = 64, kSY = 16;          // source tile
-constexpr int kWW = 96, kWH = 48;          // LDS window
-constexpr int kPix = kSY / (kBlock / kSX); // source pixels per lane (4)
+constexpr int kWinCells = 15360;           // LDS window capacity (60 KB)
+constexpr int kWW = 96, kWH = 48;          // fallback window when the bounding box does not fit
+constexpr int kSplatThreads = kSX * kSY;   // one lane per source pixel: 16 waves, two workgroups (120 KB LDS) fill a CU
 constexpr float kFix = 2097152.f;          // 2^21
 constexpr float kUnfix = 1.f / 2097152.f;
 static_assert(kSX * kSY <= 1024, "fixed-point headroom assumes <= 1024 source pixels per window");
+static_assert(kWW * kWH <= kWinCells, "fallback window must fit");
 
 __device__ inline float gauss(float d) {   // exp(-d*d/2) through v_exp_f32
   return __builtin_amdgcn_exp2f(d * d * -0.72134752044448170368f);
 }
 
-__global__ __launch_bounds__(kBlock) void forward_warp_fwd_kernel(const float2 *__restrict__ flows,
-                                                                  float *__restrict__ output, int H, int W) {
-  __shared__ unsigned win[kWW * kWH];
+__global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const float2 *__restrict__ flows,
+                                                                         float *__restrict__ output, int H, int W) {
+  __shared__ unsigned win[kWinCells];
+  __shared__ int box[4];                     // min_x, min_y, -max_x, -max_y (all reduced with atomicMin)
   const int x0 = blockIdx.x * kSX, y0 = blockIdx.y * kSY;
   const long long item = (long long)blockIdx.z * H * W;
   float *out = output + item;
-  // window origin from the tile-centre pixel (robust against outlier flows)
+
+  const int sx = x0 + (threadIdx.x % kSX), sy = y0 + threadIdx.x / kSX;
+  Window w;
+  w.any = false;
+  if (sx < W && sy < H) w = splat_window(sx, sy, flows[item + (long long)sy * W + sx], H, W);
+
+  // First guess (free for a coherent flow): a 96x48 window centred on where the
+  // tile-centre pixel lands.  Only if some lane's patch misses it is the tile's
+  // bounding box reduced (wave shuffles, then one LDS atomic per wave) and, when it
+  // fits the LDS capacity, used as the window instead.
   const int cxp = min(x0 + kSX / 2, W - 1), cyp = min(y0 + kSY / 2, H - 1);
   const float2 fc = flows[item + (long long)cyp * W + cxp];
   // clamped so that a NaN/huge centre flow still gives a usable (if useless) window
-  const int wx0 = (int)fminf(fmaxf(floorf((float)cxp + fc.x), -1e6f), 1e6f) - kWW / 2;
-  const int wy0 = (int)fminf(fmaxf(floorf((float)cyp + fc.y), -1e6f), 1e6f) - kWH / 2;
-  for (int i = threadIdx.x; i < kWW * kWH; i += kBlock) win[i] = 0u;
+  int wx0 = (int)fminf(fmaxf(floorf((float)cxp + fc.x), -1e6f), 1e6f) - kWW / 2;
+  int wy0 = (int)fminf(fmaxf(floorf((float)cyp + fc.y), -1e6f), 1e6f) - kWH / 2;
+  int ww = kWW, wh = kWH;
+  const bool miss = w.any && !(w.min_x >= wx0 && w.max_x < wx0 + kWW && w.min_y >= wy0 && w.max_y < wy0 + kWH);
+  if (threadIdx.x < 4) box[threadIdx.x] = 0x7fffffff;
+  if (__syncthreads_or(miss)) {
+    int b0 = w.any ? w.min_x : 0x7fffffff, b1 = w.any ? w.min_y : 0x7fffffff;
+    int b2 = w.any ? -w.max_x : 0x7fffffff, b3 = w.any ? -w.max_y : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      b0 = min(b0, __shfl_xor(b0, off, 64));
+      b1 = min(b1, __shfl_xor(b1, off, 64));
+      b2 = min(b2, __shfl_xor(b2, off, 64));
+      b3 = min(b3, __shfl_xor(b3, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && b0 != 0x7fffffff) {
+      atomicMin(&box[0], b0);
+      atomicMin(&box[1], b1);
+      atomicMin(&box[2], b2);
+      atomicMin(&box[3], b3);
+    }
+    __syncthreads();
+    const int bw = -box[2] - box[0] + 1, bh = -box[3] - box[1] + 1;
+    if (box[0] != 0x7fffffff && (long long)bw * bh <= kWinCells) {
+      wx0 = box[0];
+      wy0 = box[1];
+      ww = bw;
+      wh = bh;
+    }
+  }
+  const int cells = ww * wh;
+  for (int i = threadIdx.x; i < cells; i += kSplatThreads) win[i] = 0u;
   __syncthreads();
 
-  const int sx = x0 + (threadIdx.x % kSX);
-  const int sy_base = y0 + threadIdx.x / kSX;
-#pragma unroll
-  for (int i = 0; i < kPix; ++i) {
-    const int sy = sy_base + i * (kBlock / kSX);
-    if (sx >= W || sy >= H) continue;
-    const Window w = splat_window(sx, sy, flows[item + (long long)sy * W + sx], H, W);
-    if (!w.any) continue;
+  if (w.any) {
     float ex[9];
 #pragma unroll
     for (int a = 0; a < 9; ++a) ex[a] = gauss((float)(w.min_x + a) - w.tx);
     const int lx0 = w.min_x - wx0, ly0 = w.min_y - wy0;
     const int nx = w.max_x - w.min_x, ny = w.max_y - w.min_y;   // taps - 1 per axis (<= 8)
-    const bool inside = lx0 >= 0 && lx0 + nx < kWW && ly0 >= 0 && ly0 + ny < kWH;
+    const bool inside = lx0 >= 0 && lx0 + nx < ww && ly0 >= 0 && ly0 + ny < wh;
     if (inside) {
-      unsigned *wp = win + ly0 * kWW + lx0;
+      unsigned *wp = win + ly0 * ww + lx0;
 #pragma unroll
       for (int r = 0; r < 9; ++r) {
         if (r > ny) break;
         const float ey = gauss((float)(w.min_y + r) - w.ty) * kFix;
 #pragma unroll
         for (int a = 0; a < 9; ++a)
-          if (a <= nx) atomicAdd(wp + r * kWW + a, (unsigned)__float2uint_rn(ex[a] * ey));
+          if (a <= nx) atomicAdd(wp + r * ww + a, (unsigned)__float2uint_rn(ex[a] * ey));
       }
     } else {
       for (int r = 0; r <= ny; ++r) {
         const int n_y = w.min_y + r;
         const float ey = gauss((float)n_y - w.ty);
         const int ly = ly0 + r;
-        const bool rowin = ly >= 0 && ly < kWH;
+        const bool rowin = ly >= 0 && ly < wh;
 #pragma unroll
         for (int a = 0; a < 9; ++a) {
           if (a > nx) break;
           const float weight = ex[a] * ey;
           const int lx = lx0 + a;
-          if (rowin && lx >= 0 && lx < kWW)
-            atomicAdd(&win[ly * kWW + lx], (unsigned)__float2uint_rn(weight * kFix));
+          if (rowin && lx >= 0 && lx < ww)
+            atomicAdd(&win[ly * ww + lx], (unsigned)__float2uint_rn(weight * kFix));
           else
             unsafeAtomicAdd(out + (long long)n_y * W + w.min_x + a, weight);
         }
@@ -397,11 +433,15 @@ __global__ __launch_bounds__(kBlock) void forward_warp_fwd_kernel(const float2 *
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < kWW * kWH; i += kBlock) {
-    const unsigned v = win[i];
-    const int gy = wy0 + i / kWW, gx = wx0 + i % kWW;
-    if (v != 0u && gy >= 0 && gy < H && gx >= 0 && gx < W)
-      unsafeAtomicAdd(out + (long long)gy * W + gx, (float)v * kUnfix);
+  // flush: wave r takes window rows r, r+16, ...; lanes walk the row (no runtime division)
+  for (int ly = threadIdx.x >> 6; ly < wh; ly += kSplatThreads / 64) {
+    const int gy = wy0 + ly;
+    if (gy < 0 || gy >= H) continue;
+    for (int lx = threadIdx.x & 63; lx < ww; lx += 64) {
+      const unsigned v = win[ly * ww + lx];
+      const int gx = wx0 + lx;
+      if (v != 0u && gx >= 0 && gx < W) unsafeAtomicAdd(out + (long long)gy * W + gx, (float)v * kUnfix);
+    }
   }
 }
 
@@ -573,7 +613,7 @@ extern "C" int unflow_forward_warp_fwd(const float *flows, float *output, int B,
   hipStream_t s = as_stream(stream);
   if (hipMemsetAsync(output, 0, sizeof(float) * (size_t)total, s) != hipSuccess)
     return launch_status("forward_warp_fwd memset");
-  hipLaunchKernelGGL(forward_warp_fwd_kernel, dim3((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B), dim3(kBlock), 0, s,
+  hipLaunchKernelGGL(forward_warp_fwd_kernel, dim3((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B), dim3(kSplatThreads), 0, s,
                      reinterpret_cast<const float2 *>(flows), output, H, W);
   return launch_status("forward_warp_fwd");
 }
