@@ -276,6 +276,14 @@ def breakdown(wl, fwd_ms, bwd_ms):
     rows.append(("ternary fwd 7x7", timeit(tern), npx * 28))
     loss = tern()
     rows.append(("ternary bwd 7x7", timeit(lambda: torch.autograd.grad(loss, x, retain_graph=True)), npx * 40))
+    for name, fn in (("smoothness_loss", losses.smoothness_loss), ("second_order_loss", losses.second_order_loss)):
+        f = ffw.clone().requires_grad_(True)
+        rows.append((name + " fwd", timeit(lambda: fn(f)), npx * 8))
+        ls = fn(f)
+        rows.append((name + " bwd", timeit(lambda: torch.autograd.grad(ls, f, retain_graph=True)), npx * 16))
+    gl = losses.gradient_loss(wl.im1, x, wl.border)
+    rows.append(("gradient_loss fwd", timeit(lambda: losses.gradient_loss(wl.im1, x, wl.border)), npx * 28))
+    rows.append(("gradient_loss bwd", timeit(lambda: torch.autograd.grad(gl, x, retain_graph=True)), npx * 40))
     rows.append(("fb_occlusion", timeit(lambda: losses.fb_occlusion(ffw, fbw)), npx * 28))
     rows.append(("downsample x2 C3", timeit(lambda: ops.downsample(wl.im1, 2)), npx * 15))
     a = torch.empty(256 * 1024 * 1024, device=ffw.device)

@@ -147,6 +147,36 @@ int unflow_charbonnier_bwd(const float *x, const float *mask, int mask_channels,
                            float epsilon, float truncate, long long norm_count,
                            unflow_stream_t stream);
 
+/* ---------------------------------------------------------------- 3x3 stencil terms
+ * smoothness_loss (order 1, src/e2eflow/core/losses.py:206-225,250-255) and
+ * second_order_loss (order 2, losses.py:258-295): charbonnier of the masked
+ * first / second differences of both flow components, fused.  flow [B,H,W,2].
+ *   loss: device scalar, overwritten with (loss_u + loss_v) =
+ *         sum / norm_count; norm_count 0 = the local B*H*W*K, K = 2 (order 1)
+ *         or 4 (order 2).  workspace as for the census loss.
+ * _bwd: dflow [B,H,W,2] overwritten with d loss / d flow * gout (NULL = 1). */
+int unflow_smoothness_loss_fwd(const float *flow, float *loss, float *workspace, int B, int H, int W,
+                               int order, long long norm_count, unflow_stream_t stream);
+int unflow_smoothness_loss_bwd(const float *flow, const float *gout, float *dflow, int B, int H, int W,
+                               int order, long long norm_count, unflow_stream_t stream);
+/* _smoothness_deltas / _second_order_deltas (losses.py:206-225,258-287):
+ * delta_u, delta_v, mask [B,H,W,K]; any of them may be NULL. */
+int unflow_smoothness_deltas(const float *flow, float *delta_u, float *delta_v, float *mask, int B,
+                             int H, int W, int order, unflow_stream_t stream);
+/* gradient_loss (losses.py:244-247): charbonnier of the masked difference of the
+ * Sobel gradients of im1 and im2_warped ([B,H,W,3]); mask [B,H,W,1].
+ * norm_count 0 = local B*H*W*6.  _bwd: gradient wrt im2_warped only (im1 carries
+ * no gradient in the reference's graph). */
+int unflow_gradient_loss_fwd(const float *im1, const float *im2_warped, const float *mask,
+                             float *loss, float *workspace, int B, int H, int W,
+                             long long norm_count, unflow_stream_t stream);
+int unflow_gradient_loss_bwd(const float *im1, const float *im2_warped, const float *mask,
+                             const float *gout, float *d_im2_warped, int B, int H, int W,
+                             long long norm_count, unflow_stream_t stream);
+/* _gradient_delta (losses.py:228-241): diff [B,H,W,6], channel 2c = d/dx, 2c+1 = d/dy of colour c. */
+int unflow_gradient_delta(const float *im1, const float *im2_warped, float *diff, int B, int H, int W,
+                          unflow_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

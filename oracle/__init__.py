@@ -44,6 +44,8 @@ def lib():
         L = ctypes.CDLL(_SO)
         L.oracle_charbonnier_fwd.restype = ctypes.c_double
         L.oracle_ternary_loss_fwd.restype = ctypes.c_double
+        L.oracle_smoothness_loss_fwd.restype = ctypes.c_double
+        L.oracle_gradient_loss_fwd.restype = ctypes.c_double
         L.oracle_num_threads.restype = ctypes.c_int
         L.oracle_border_size.restype = ctypes.c_int
         L.oracle_border_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_float]
@@ -247,14 +249,75 @@ def ternary_loss_grad(im1, im2_warped, mask, max_distance=1, gout=1.0):
     return d
 
 
+# --------------------------------------------------------------------------- 3x3 stencil terms
+def smoothness_deltas(flow, order=1):
+    """_smoothness_deltas (order 1, losses.py:206-225) / _second_order_deltas (order 2, :258-287):
+    (delta_u, delta_v, mask), each [B,H,W,K], K = 2 or 4."""
+    flow = _f32(flow)
+    B, H, W, C = flow.shape
+    assert C == 2
+    K = 2 if order == 1 else 4
+    du, dv, m = (np.empty((B, H, W, K), np.float32) for _ in range(3))
+    rc = lib().oracle_smoothness_deltas(_p(flow), _p(du), _p(dv), _p(m), B, H, W, order)
+    if rc:
+        raise ValueError("order must be 1 or 2")
+    return du, dv, m
+
+
+def smoothness_loss(flow, order=1, norm_count=0):
+    """smoothness_loss (order 1, losses.py:250-255) / second_order_loss (order 2, :290-295)."""
+    flow = _f32(flow)
+    B, H, W, _ = flow.shape
+    return lib().oracle_smoothness_loss_fwd(_p(flow), B, H, W, order, ctypes.c_double(norm_count))
+
+
+def smoothness_loss_grad(flow, order=1, gout=1.0, norm_count=0):
+    flow = _f32(flow)
+    B, H, W, _ = flow.shape
+    d = np.empty_like(flow)
+    lib().oracle_smoothness_loss_bwd(_p(flow), ctypes.c_float(gout), _p(d), B, H, W, order,
+                                     ctypes.c_double(norm_count))
+    return d
+
+
+def second_order_loss(flow, norm_count=0):
+    return smoothness_loss(flow, 2, norm_count)
+
+
+def gradient_delta(im1, im2_warped):
+    """_gradient_delta (losses.py:228-241): [B,H,W,6]."""
+    im1, im2_warped = _f32(im1), _f32(im2_warped)
+    B, H, W, C = im1.shape
+    assert C == 3
+    diff = np.empty((B, H, W, 6), np.float32)
+    lib().oracle_gradient_delta(_p(im1), _p(im2_warped), _p(diff), B, H, W)
+    return diff
+
+
+def gradient_loss(im1, im2_warped, mask, norm_count=0):
+    """gradient_loss (losses.py:244-247)."""
+    im1, im2_warped, mask = _f32(im1), _f32(im2_warped), _f32(mask)
+    B, H, W, _ = im1.shape
+    return lib().oracle_gradient_loss_fwd(_p(im1), _p(im2_warped), _p(mask), B, H, W,
+                                          ctypes.c_double(norm_count))
+
+
+def gradient_loss_grad(im1, im2_warped, mask, gout=1.0, norm_count=0):
+    im1, im2_warped, mask = _f32(im1), _f32(im2_warped), _f32(mask)
+    B, H, W, _ = im1.shape
+    d = np.empty_like(im2_warped)
+    lib().oracle_gradient_loss_bwd(_p(im1), _p(im2_warped), _p(mask), ctypes.c_float(gout), _p(d), B, H, W,
+                                   ctypes.c_double(norm_count))
+    return d
+
+
 # --------------------------------------------------------------------------- composite
 DISOCC_THRESH = 0.8  # losses.py:9
 
 
 def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion="",
                    data_max_distance=1):
-    """Hot subset of losses.py:16-87: warps, masks, 'occ', 'fb', 'ternary' and
-    the disocclusion maps.  Returns (losses, aux)."""
+    """compute_losses (losses.py:16-87), all eight entries.  Returns (losses, aux)."""
     im2_warped = image_warp(im2, flow_fw)
     im1_warped = image_warp(im1, flow_bw)
     disocc_fw = (forward_warp(flow_fw) < DISOCC_THRESH).astype(np.float32)
@@ -281,6 +344,9 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
         "occ": charbonnier_loss(occ_fw) + charbonnier_loss(occ_bw),
         "photo": charbonnier_loss(_f32(im1) - im2_warped, mask_fw, beta=255) +
                  charbonnier_loss(_f32(im2) - im1_warped, mask_bw, beta=255),
+        "grad": gradient_loss(im1, im2_warped, mask_fw) + gradient_loss(im2, im1_warped, mask_bw),
+        "smooth_1st": smoothness_loss(flow_fw, 1) + smoothness_loss(flow_bw, 1),
+        "smooth_2nd": smoothness_loss(flow_fw, 2) + smoothness_loss(flow_bw, 2),
         "fb": charbonnier_loss(flow_diff_fw, mask_fw) + charbonnier_loss(flow_diff_bw, mask_bw),
         "ternary": ternary_loss(im1, im2_warped, mask_fw, data_max_distance) +
                    ternary_loss(im2, im1_warped, mask_bw, data_max_distance),

@@ -196,6 +196,53 @@ def ternary_loss(im1, im2_warped, mask, max_distance=1):
     return charbonnier(dist, np.asarray(mask, np.float64) * tm)
 
 
+def _shift(a, dy, dx):
+    """a[y+dy, x+dx] with zeros outside (NHWC, conv2d SAME)."""
+    B, H, W, C = a.shape
+    p = np.zeros((B, H + 2, W + 2, C), a.dtype)
+    p[:, 1:-1, 1:-1] = a
+    return p[:, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+
+
+def smoothness_loss(flow, order=1):
+    """losses.py:206-225,250-255 (order 1) and :258-295 (order 2), float64, by array shifts."""
+    f = np.asarray(flow, np.float64)
+    B, H, W, _ = f.shape
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    if order == 1:
+        deltas = [f - _shift(f, 0, 1), f - _shift(f, 1, 0)]
+        masks = [xx < W - 1, yy < H - 1]
+    else:
+        mx, my = (xx >= 1) & (xx < W - 1), (yy >= 1) & (yy < H - 1)
+        deltas = [_shift(f, 0, -1) - 2 * f + _shift(f, 0, 1), _shift(f, -1, 0) - 2 * f + _shift(f, 1, 0),
+                  _shift(f, -1, -1) - 2 * f + _shift(f, 1, 1), _shift(f, -1, 1) - 2 * f + _shift(f, 1, -1)]
+        masks = [mx, my, mx & my, mx & my]
+    K = len(deltas)
+    total = 0.0
+    for d, m in zip(deltas, masks):
+        total += ((d ** 2 + 1e-6) ** 0.45 * m[None, :, :, None]).sum()
+    return total / (B * H * W * K)      # loss_u + loss_v, each normalised by B*H*W*K
+
+
+def gradient_loss(im1, im2_warped, mask):
+    """losses.py:228-247, float64."""
+    a, b = np.asarray(im1, np.float64), np.asarray(im2_warped, np.float64)
+    B, H, W, _ = a.shape
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    mx, my = (xx >= 1) & (xx < W - 1), (yy >= 1) & (yy < H - 1)
+
+    def sobel(z):
+        gx = sum(w * (_shift(z, dy, 1) - _shift(z, dy, -1)) for dy, w in ((-1, 1), (0, 2), (1, 1)))
+        gy = sum(w * (_shift(z, 1, dx) - _shift(z, -1, dx)) for dx, w in ((-1, 1), (0, 2), (1, 1)))
+        return gx, gy
+    ax, ay = sobel(a)
+    bx, by = sobel(b)
+    m = np.asarray(mask, np.float64)
+    ex = ((ax - bx) ** 2 + 1e-6) ** 0.45 * m * mx[None, :, :, None]
+    ey = ((ay - by) ** 2 + 1e-6) ** 0.45 * m * my[None, :, :, None]
+    return (ex.sum() + ey.sum()) / (B * H * W * 6)
+
+
 def numeric_grad(fn, x, eps=1e-3):
     """Central-difference gradient of scalar fn wrt array x (float64)."""
     x = np.array(x, np.float64)

@@ -20,13 +20,18 @@
  *                             gradients TF autodiff derives from it)
  *   oracle_ternary_loss_*     src/e2eflow/core/losses.py:90-122 (soft census)
  *   oracle_charbonnier_*      src/e2eflow/core/losses.py:298-322
+ *   oracle_smoothness_*       src/e2eflow/core/losses.py:206-225,250-295
+ *                             (_smoothness_deltas / _second_order_deltas,
+ *                             smoothness_loss / second_order_loss)
+ *   oracle_gradient_*         src/e2eflow/core/losses.py:228-247
+ *                             (_gradient_delta, gradient_loss)
  *   oracle_create_*_mask      src/e2eflow/core/losses.py:325-366
  *   oracle_fb_occlusion       src/e2eflow/core/losses.py:38-51
  *
  * Pinning status (see DESIGN.md "Oracle"):
  *   pinned by the reference's own known-answer tests (tests/golden/reference_kat.json):
  *     backward_warp fwd, image_warp fwd, correlation (k=1, md=0), downsample,
- *     create_outgoing_mask.
+ *     create_outgoing_mask, _smoothness_deltas (+ mask), gradient_loss.
  *   PARITY UNPINNED (no reference fixture exists; pinned only by formula, an
  *   independent numpy restatement and numeric-gradient self-consistency):
  *     soft census / ternary_loss, forward_warp forward values, correlation
@@ -861,4 +866,177 @@ void oracle_ternary_loss_bwd(const float *im1, const float *im2_warped, const fl
   free(g1);
   free(g2);
   free(dgray);
+}
+
+/* ---------------------------------------------------------------------------
+ * 3x3 stencil terms of compute_losses: smoothness_loss, second_order_loss,
+ * gradient_loss (losses.py:206-295).  tf.nn.conv2d SAME = cross-correlation
+ * with zero padding: out[y,x] = sum_{i,j} in[y+i-1, x+j-1] * w[i][j]; the taps
+ * are summed in row-major order, zero weights skipped (weights are 0, +-1, +-2,
+ * so every product is exact and only the order of the additions matters).
+ * ------------------------------------------------------------------------- */
+static const float kFlowFilters1[2][9] = {
+    {0, 0, 0, 0, 1, -1, 0, 0, 0}, /* losses.py:212  filter_x */
+    {0, 0, 0, 0, 1, 0, 0, -1, 0}, /* losses.py:213  filter_y */
+};
+static const float kFlowFilters2[4][9] = {
+    {0, 0, 0, 1, -2, 1, 0, 0, 0}, /* losses.py:266-268 filter_x */
+    {0, 1, 0, 0, -2, 0, 0, 1, 0}, /* :269-271 filter_y */
+    {1, 0, 0, 0, -2, 0, 0, 0, 1}, /* :272-274 filter_diag1 */
+    {0, 0, 1, 0, -2, 0, 1, 0, 0}, /* :275-277 filter_diag2 */
+};
+static const float kSobelX[9] = {-1, 0, 1, -2, 0, 2, -1, 0, 1}; /* losses.py:230 */
+static const float kSobelY[9] = {-1, -2, -1, 0, 0, 0, 1, 2, 1}; /* its transpose, :231 */
+
+/* one output of conv2d SAME on channel c of an NHWC tensor with `C` channels */
+static inline float conv3x3_at(const float *in, int H, int W, int C, int c, int y, int x, const float *w) {
+  float s = 0.0f;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      if (w[i * 3 + j] == 0.0f) continue;
+      const int yy = y + i - 1, xx = x + j - 1;
+      if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+      s = s + in[((size_t)yy * W + xx) * C + c] * w[i * 3 + j];
+    }
+  return s;
+}
+
+/* mask channel k of _smoothness_deltas (order 1, :208-210) / _second_order_deltas (order 2, :260-263) */
+static inline float flow_delta_mask(int order, int k, int H, int W, int y, int x) {
+  if (order == 1) return k == 0 ? (x < W - 1 ? 1.0f : 0.0f) : (y < H - 1 ? 1.0f : 0.0f);
+  const int mx = x >= 1 && x < W - 1, my = y >= 1 && y < H - 1;
+  return k == 0 ? (float)mx : (k == 1 ? (float)my : (float)(mx && my));
+}
+
+/* delta_u, delta_v, mask: [B,H,W,K], K = 2 (order 1) or 4 (order 2) */
+int oracle_smoothness_deltas(const float *flow, float *delta_u, float *delta_v, float *mask, int B, int H,
+                             int W, int order) {
+  if (order != 1 && order != 2) return 1;
+  const int K = order == 1 ? 2 : 4;
+  for (int b = 0; b < B; b++) {
+    const float *f = flow + (size_t)b * H * W * 2;
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++)
+        for (int k = 0; k < K; k++) {
+          const float *w = order == 1 ? kFlowFilters1[k] : kFlowFilters2[k];
+          const size_t o = (((size_t)b * H + y) * W + x) * K + k;
+          if (delta_u) delta_u[o] = conv3x3_at(f, H, W, 2, 0, y, x, w);
+          if (delta_v) delta_v[o] = conv3x3_at(f, H, W, 2, 1, y, x, w);
+          if (mask) mask[o] = flow_delta_mask(order, k, H, W, y, x);
+        }
+  }
+  return 0;
+}
+
+/* smoothness_loss (order 1, :250-255) / second_order_loss (order 2, :290-295):
+   charbonnier_loss(delta_u, mask) + charbonnier_loss(delta_v, mask).  norm_count
+   (0 = B*H*W*K) is the normalisation the GLOBAL batch gives. */
+double oracle_smoothness_loss_fwd(const float *flow, int B, int H, int W, int order, double norm_count) {
+  const int K = order == 1 ? 2 : 4;
+  const size_t n = (size_t)B * H * W * K;
+  float *du = (float *)malloc(n * sizeof(float)), *dv = (float *)malloc(n * sizeof(float));
+  float *m = (float *)malloc(n * sizeof(float));
+  oracle_smoothness_deltas(flow, du, dv, m, B, H, W, order);
+  const double scale = norm_count > 0 ? (double)n / norm_count : 1.0;
+  const double l = oracle_charbonnier_fwd(du, m, K, B, H, W, K, 0.45f, 1.0f, 0.001f, 0.0f) +
+                   oracle_charbonnier_fwd(dv, m, K, B, H, W, K, 0.45f, 1.0f, 0.001f, 0.0f);
+  free(du); free(dv); free(m);
+  return l * scale;
+}
+
+void oracle_smoothness_loss_bwd(const float *flow, float gout, float *dflow, int B, int H, int W, int order,
+                                double norm_count) {
+  const int K = order == 1 ? 2 : 4;
+  const size_t n = (size_t)B * H * W * K;
+  float *du = (float *)malloc(n * sizeof(float)), *dv = (float *)malloc(n * sizeof(float));
+  float *m = (float *)malloc(n * sizeof(float));
+  float *gu = (float *)malloc(n * sizeof(float)), *gv = (float *)malloc(n * sizeof(float));
+  oracle_smoothness_deltas(flow, du, dv, m, B, H, W, order);
+  const float g = (float)(norm_count > 0 ? (double)gout * (double)n / norm_count : (double)gout);
+  oracle_charbonnier_bwd(du, m, K, g, gu, B, H, W, K, 0.45f, 1.0f, 0.001f, 0.0f);
+  oracle_charbonnier_bwd(dv, m, K, g, gv, B, H, W, K, 0.45f, 1.0f, 0.001f, 0.0f);
+  /* transpose of the convolution: d in[y+i-1, x+j-1] += w[i][j] * d out[y,x] */
+  memset(dflow, 0, (size_t)B * H * W * 2 * sizeof(float));
+  for (int b = 0; b < B; b++)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++)
+        for (int k = 0; k < K; k++) {
+          const float *w = order == 1 ? kFlowFilters1[k] : kFlowFilters2[k];
+          const size_t o = (((size_t)b * H + y) * W + x) * K + k;
+          for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+              const int yy = y + i - 1, xx = x + j - 1;
+              if (w[i * 3 + j] == 0.0f || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+              float *d = dflow + (((size_t)b * H + yy) * W + xx) * 2;
+              d[0] += w[i * 3 + j] * gu[o];
+              d[1] += w[i * 3 + j] * gv[o];
+            }
+        }
+  free(du); free(dv); free(m); free(gu); free(gv);
+}
+
+/* _gradient_delta (:228-241): conv2d(im1, sobel) - conv2d(im2_warped, sobel), [B,H,W,6],
+   channel 2c = d/dx of image channel c, 2c+1 = d/dy. */
+void oracle_gradient_delta(const float *im1, const float *im2_warped, float *diff, int B, int H, int W) {
+  for (int b = 0; b < B; b++) {
+    const float *a = im1 + (size_t)b * H * W * 3, *c2 = im2_warped + (size_t)b * H * W * 3;
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++)
+        for (int c = 0; c < 3; c++) {
+          float *o = diff + (((size_t)b * H + y) * W + x) * 6 + 2 * c;
+          o[0] = conv3x3_at(a, H, W, 3, c, y, x, kSobelX) - conv3x3_at(c2, H, W, 3, c, y, x, kSobelX);
+          o[1] = conv3x3_at(a, H, W, 3, c, y, x, kSobelY) - conv3x3_at(c2, H, W, 3, c, y, x, kSobelY);
+        }
+  }
+}
+
+/* mask * tile(concat(mask_x, mask_y), 3)  (:244-247) as a 6-channel mask */
+static float *gradient_mask6(const float *mask, int B, int H, int W) {
+  float *m6 = (float *)malloc((size_t)B * H * W * 6 * sizeof(float));
+  for (int b = 0; b < B; b++)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        const size_t p = ((size_t)b * H + y) * W + x;
+        const float mx = (x >= 1 && x < W - 1) ? 1.0f : 0.0f, my = (y >= 1 && y < H - 1) ? 1.0f : 0.0f;
+        for (int k = 0; k < 6; k++) m6[p * 6 + k] = mask[p] * ((k & 1) ? my : mx);
+      }
+  return m6;
+}
+
+double oracle_gradient_loss_fwd(const float *im1, const float *im2_warped, const float *mask, int B, int H,
+                                int W, double norm_count) {
+  const size_t n = (size_t)B * H * W * 6;
+  float *diff = (float *)malloc(n * sizeof(float));
+  float *m6 = gradient_mask6(mask, B, H, W);
+  oracle_gradient_delta(im1, im2_warped, diff, B, H, W);
+  const double l = oracle_charbonnier_fwd(diff, m6, 6, B, H, W, 6, 0.45f, 1.0f, 0.001f, 0.0f);
+  free(diff); free(m6);
+  return norm_count > 0 ? l * (double)n / norm_count : l;
+}
+
+/* d loss / d im2_warped (im1 carries no gradient in the reference's graph) */
+void oracle_gradient_loss_bwd(const float *im1, const float *im2_warped, const float *mask, float gout,
+                              float *d_im2_warped, int B, int H, int W, double norm_count) {
+  const size_t n = (size_t)B * H * W * 6;
+  float *diff = (float *)malloc(n * sizeof(float)), *gd = (float *)malloc(n * sizeof(float));
+  float *m6 = gradient_mask6(mask, B, H, W);
+  oracle_gradient_delta(im1, im2_warped, diff, B, H, W);
+  const float g = (float)(norm_count > 0 ? (double)gout * (double)n / norm_count : (double)gout);
+  oracle_charbonnier_bwd(diff, m6, 6, g, gd, B, H, W, 6, 0.45f, 1.0f, 0.001f, 0.0f);
+  memset(d_im2_warped, 0, (size_t)B * H * W * 3 * sizeof(float));
+  for (int b = 0; b < B; b++)
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++)
+        for (int c = 0; c < 3; c++) {
+          const size_t o = (((size_t)b * H + y) * W + x) * 6 + 2 * c;
+          for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+              const int yy = y + i - 1, xx = x + j - 1;
+              if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+              /* diff = conv(im1) - conv(im2_warped) */
+              d_im2_warped[(((size_t)b * H + yy) * W + xx) * 3 + c] -=
+                  kSobelX[i * 3 + j] * gd[o] + kSobelY[i * 3 + j] * gd[o + 1];
+            }
+        }
+  free(diff); free(gd); free(m6);
 }

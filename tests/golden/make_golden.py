@@ -115,6 +115,26 @@ def reference_kat():
         flow=flow2([[3, 2, 1], [2, 1, 0], [0, -2, -1]], [[0, 0, 0], [0, 0, 0], [0, 0, 0]]),
         expected=[[0, 0, 0], [1, 1, 1], [1, 0, 1]])
 
+    # test/test_losses.py:11-41: _smoothness_deltas * mask
+    d0 = [[0, 0, 0], [-8, 5, 0], [-1, 1, 0]]
+    d1 = [[0, -8, -3], [0, 7, 3], [0, 0, 0]]
+    kat["smoothness_deltas"] = dict(
+        cite="test/test_losses.py:11-41",
+        flow=flow2([[0, 0, 0], [0, 8, 3], [0, 1, 0]], [[0, 0, 0], [0, 8, 3], [0, 1, 0]]),
+        mask0=[[1, 1, 0], [1, 1, 0], [1, 1, 0]], mask1=[[1, 1, 1], [1, 1, 1], [0, 0, 0]],
+        delta_u0=d0, delta_u1=d1, delta_v0=d0, delta_v1=d1)
+
+    # test/test_losses.py:97-121: gradient_loss of an image and the same image + 1 is ~0
+    def im3(rows):
+        im = np.ones([1, 3, 3, 3], np.float32)
+        for c in range(3):
+            im[0, :, :, c] = rows
+        return im.tolist()
+    kat["gradient_loss"] = dict(
+        cite="test/test_losses.py:97-121",
+        im1=im3([[0, 1, 0], [0, 2, 0], [0, 3, 4]]), im2=im3([[1, 2, 1], [1, 3, 1], [1, 4, 5]]),
+        expected=0.0, atol=1e-2)
+
     # test/ops/forward_warp.py:9-19 holds no values, only the shape of its
     # gradient check ([1,10,10,2] flow, rtol=atol=1e-3).
     kat["forward_warp_gradcheck"] = dict(cite="test/ops/forward_warp.py:9-19",
@@ -191,6 +211,19 @@ def oracle_seeded():
         out["ternary_loss_r%d" % r] = np.float64(loss)
         out["ternary_dist_r%d" % r] = dist
         out["ternary_grad_r%d" % r] = oracle.ternary_loss_grad(im1, out["image_warp"], mask, r)
+
+    # 3x3 stencil terms (smoothness, second order, gradient loss) on the same pair
+    for order in (1, 2):
+        l = oracle.smoothness_loss(flow, order)
+        ref = np_ref.smoothness_loss(flow, order)
+        assert abs(l - ref) <= 1e-6 * abs(ref), (l, ref)
+        out["smooth_loss_o%d" % order] = np.float64(l)
+        out["smooth_grad_o%d" % order] = oracle.smoothness_loss_grad(flow, order)
+    l = oracle.gradient_loss(im1, out["image_warp"], mask)
+    ref = np_ref.gradient_loss(im1, out["image_warp"], mask)
+    assert abs(l - ref) <= 1e-6 * abs(ref), (l, ref)
+    out["gradient_loss"] = np.float64(l)
+    out["gradient_loss_grad"] = oracle.gradient_loss_grad(im1, out["image_warp"], mask)
     return out
 
 

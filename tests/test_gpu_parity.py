@@ -115,6 +115,44 @@ def test_seeded_census(seeded, dev, r):
     close(im2w.grad, want, 1e-4, 1e-4 * np.abs(want).max())  # gradients: reference checks at 1e-3
 
 
+def test_smoothness_deltas_known_answer(kat, dev):
+    """test/test_losses.py:11-41 of the reference through the HIP path, exact."""
+    from unflow_amd import losses
+    k = kat["smoothness_deltas"]
+    du, dv, m = (N(t) for t in losses._smoothness_deltas(T(k["flow"], dev)))
+    np.testing.assert_array_equal(m[0, :, :, 0], k["mask0"])
+    np.testing.assert_array_equal(m[0, :, :, 1], k["mask1"])
+    for name, d in (("delta_u", du), ("delta_v", dv)):
+        np.testing.assert_array_equal((d * m)[0, :, :, 0], k[name + "0"])
+        np.testing.assert_array_equal((d * m)[0, :, :, 1], k[name + "1"])
+
+
+def test_gradient_loss_known_answer(kat, dev):
+    """test/test_losses.py:97-121."""
+    from unflow_amd import losses
+    k = kat["gradient_loss"]
+    loss = float(losses.gradient_loss(T(k["im1"], dev), T(k["im2"], dev), torch.ones((1, 3, 3, 1), device=dev)))
+    assert abs(loss - k["expected"]) <= k["atol"]
+    np.testing.assert_allclose(loss, (0.001 ** 2) ** 0.45 * 18 / 54, rtol=1e-5)
+
+
+def test_seeded_stencil_terms(seeded, dev):
+    from unflow_amd import losses
+    for order, fn in ((1, losses.smoothness_loss), (2, losses.second_order_loss)):
+        flow = T(seeded["flow"], dev).requires_grad_(True)
+        loss = fn(flow)
+        np.testing.assert_allclose(float(loss.detach()), float(seeded["smooth_loss_o%d" % order]), rtol=1e-5)
+        loss.backward()
+        want = seeded["smooth_grad_o%d" % order]
+        close(flow.grad, want, 1e-4, 1e-5 * np.abs(want).max())
+    im1, im2w = T(seeded["im1"], dev), T(seeded["image_warp"], dev).requires_grad_(True)
+    loss = losses.gradient_loss(im1, im2w, T(seeded["border_mask"], dev))
+    np.testing.assert_allclose(float(loss.detach()), float(seeded["gradient_loss"]), rtol=1e-5)
+    loss.backward()
+    want = seeded["gradient_loss_grad"]
+    close(im2w.grad, want, 1e-4, 1e-5 * np.abs(want).max())
+
+
 # ----------------------------------------------------------------------------- fresh inputs vs oracle
 @pytest.mark.parametrize("shape,attrs", [
     ((2, 32, 16, 24), dict()),                                   # FlowNetC attrs
@@ -282,6 +320,42 @@ def test_charbonnier_and_masks_vs_oracle(oracle_mod, dev):
     np.testing.assert_array_equal(N(occ), wo)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 40, 56), (1, 9, 33), (3, 8, 32), (1, 1, 1), (1, 2, 70), (2, 17, 3)])
+def test_stencil_terms_vs_oracle(oracle_mod, dev, B, H, W):
+    """smoothness / second-order / gradient loss, deltas bit-exact, losses 1e-5, gradients 1e-4
+    (tile 32x8: sizes below, at and across tile borders; degenerate 1x1)."""
+    from unflow_amd import losses
+    rng = np.random.default_rng(100 + H * W)
+    flow = (rng.standard_normal((B, H, W, 2)) * 3).astype(np.float32)
+    flow[0, 0, 0] = 0      # a delta of exactly zero
+    for order, dfn, lfn in ((1, losses._smoothness_deltas, losses.smoothness_loss),
+                            (2, losses._second_order_deltas, losses.second_order_loss)):
+        want = oracle_mod.smoothness_deltas(flow, order)
+        got = dfn(T(flow, dev))
+        for g, w in zip(got, want):
+            np.testing.assert_array_equal(N(g), w)
+        f = T(flow, dev).requires_grad_(True)
+        loss = lfn(f)
+        np.testing.assert_allclose(float(loss.detach()), oracle_mod.smoothness_loss(flow, order), rtol=1e-5)
+        (loss * 3.0).backward()
+        wg = oracle_mod.smoothness_loss_grad(flow, order, gout=3.0)
+        close(f.grad, wg, 1e-4, 1e-5 * max(np.abs(wg).max(), 1e-30))
+        # a shard normalises by the global count
+        np.testing.assert_allclose(float(lfn(T(flow, dev), norm_count=7 * B * H * W)),
+                                   oracle_mod.smoothness_loss(flow, order, norm_count=7 * B * H * W), rtol=1e-5)
+    im1 = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+    im2 = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+    mask = (rng.uniform(size=(B, H, W, 1)) > 0.2).astype(np.float32)
+    np.testing.assert_array_equal(N(losses._gradient_delta(T(im1, dev), T(im2, dev))),
+                                  oracle_mod.gradient_delta(im1, im2))
+    x = T(im2, dev).requires_grad_(True)
+    loss = losses.gradient_loss(T(im1, dev), x, T(mask, dev))
+    np.testing.assert_allclose(float(loss.detach()), oracle_mod.gradient_loss(im1, im2, mask), rtol=1e-5)
+    loss.backward()
+    wg = oracle_mod.gradient_loss_grad(im1, im2, mask)
+    close(x.grad, wg, 1e-4, 1e-5 * max(np.abs(wg).max(), 1e-30))
+
+
 @pytest.mark.parametrize("mask_occlusion,use_border", [("fb", True), ("", False), ("disocc", True)])
 def test_compute_losses_vs_oracle(oracle_mod, dev, mask_occlusion, use_border):
     from unflow_amd import losses
@@ -299,7 +373,8 @@ def test_compute_losses_vs_oracle(oracle_mod, dev, mask_occlusion, use_border):
         # thresholded maps: allow a handful of pixels that sit within fp32 noise of the threshold
         assert (N(aux[k]) != waux[k]).mean() < 1e-3, k
     close(aux["im2_warped"], waux["im2_warped"])
-    for k in ("ternary", "occ", "fb", "photo", "sym"):
+    assert set(got) == {"sym", "occ", "photo", "grad", "smooth_1st", "smooth_2nd", "fb", "ternary"}  # losses.py:60-85
+    for k in ("ternary", "occ", "fb", "photo", "sym", "grad", "smooth_1st", "smooth_2nd"):
         np.testing.assert_allclose(float(got[k]), want[k], rtol=2e-4, err_msg=k)
     # backward to the flows through census -> image_warp
     got["ternary"].backward()
@@ -319,3 +394,7 @@ def test_empty_inputs(dev):
     assert ops.forward_warp(torch.zeros((0, 4, 4, 2), device=dev)).shape == (0, 4, 4, 1)
     assert ops.correlation(torch.zeros((0, 8, 4, 4), device=dev), torch.zeros((0, 8, 4, 4), device=dev)).shape == (0, 441, 4, 4)
     assert ops.downsample(torch.zeros((0, 4, 4, 3), device=dev), 2).shape == (0, 2, 2, 3)
+    from unflow_amd import losses
+    assert float(losses.smoothness_loss(torch.zeros((0, 4, 4, 2), device=dev))) == 0.0
+    assert float(losses.gradient_loss(torch.zeros((0, 4, 4, 3), device=dev), torch.zeros((0, 4, 4, 3), device=dev),
+                                      torch.zeros((0, 4, 4, 1), device=dev))) == 0.0

@@ -149,9 +149,52 @@ def test_fb_occlusion(oracle_mod):
     np.testing.assert_array_equal(diff, f + w)
 
 
+def test_smoothness_deltas_known_answer(kat, oracle_mod):
+    """test/test_losses.py:11-41 of the reference, values and masks exact."""
+    k = kat["smoothness_deltas"]
+    du, dv, m = oracle_mod.smoothness_deltas(np.asarray(k["flow"], np.float32), 1)
+    np.testing.assert_array_equal(m[0, :, :, 0], k["mask0"])
+    np.testing.assert_array_equal(m[0, :, :, 1], k["mask1"])
+    np.testing.assert_array_equal((du * m)[0, :, :, 0], k["delta_u0"])
+    np.testing.assert_array_equal((du * m)[0, :, :, 1], k["delta_u1"])
+    np.testing.assert_array_equal((dv * m)[0, :, :, 0], k["delta_v0"])
+    np.testing.assert_array_equal((dv * m)[0, :, :, 1], k["delta_v1"])
+
+
+def test_gradient_loss_known_answer(kat, oracle_mod):
+    """test/test_losses.py:97-121: an image against itself + 1 has (almost) no gradient loss."""
+    k = kat["gradient_loss"]
+    loss = oracle_mod.gradient_loss(k["im1"], k["im2"], np.ones((1, 3, 3, 1), np.float32))
+    assert abs(loss - k["expected"]) <= k["atol"]
+    # exactly: 3 colours x (column 1 for d/dx + row 1 for d/dy) = 18 unmasked entries, all with diff 0
+    np.testing.assert_allclose(loss, (0.001 ** 2) ** 0.45 * 18 / 54, rtol=1e-5)
+
+
+def test_stencil_terms_match_numpy(oracle_mod):
+    rng = np.random.default_rng(8)
+    flow = (rng.standard_normal((2, 9, 11, 2)) * 3).astype(np.float32)
+    for order in (1, 2):
+        np.testing.assert_allclose(oracle_mod.smoothness_loss(flow, order), np_ref.smoothness_loss(flow, order),
+                                   rtol=1e-6)
+    im1 = rng.uniform(size=(2, 9, 11, 3)).astype(np.float32)
+    im2 = rng.uniform(size=(2, 9, 11, 3)).astype(np.float32)
+    mask = (rng.uniform(size=(2, 9, 11, 1)) > 0.2).astype(np.float32)
+    np.testing.assert_allclose(oracle_mod.gradient_loss(im1, im2, mask), np_ref.gradient_loss(im1, im2, mask),
+                               rtol=1e-6)
+    # second-order deltas of an affine flow vanish inside the masks
+    yy, xx = np.meshgrid(np.arange(9.0), np.arange(11.0), indexing="ij")
+    aff = np.stack([2 * xx - yy + 1, 0.5 * xx + 3 * yy], -1)[None].astype(np.float32)
+    du, dv, m = oracle_mod.smoothness_deltas(aff, 2)
+    assert np.abs(du * m).max() == 0 and np.abs(dv * m).max() == 0
+    assert m[0, :, :, 2].sum() == 7 * 9 and m[0, :, :, 0].sum() == 9 * 9 and m[0, :, :, 1].sum() == 7 * 11
+
+
 def test_seeded_fixture_is_reproducible(seeded, oracle_mod):
     """The committed oracle outputs are what the oracle computes today."""
     c, p0, p1 = oracle_mod.correlation(seeded["corr_f0"], seeded["corr_f1"])
     np.testing.assert_array_equal(c, seeded["corr_out"])
     np.testing.assert_array_equal(oracle_mod.image_warp(seeded["im2"], seeded["flow"]), seeded["image_warp"])
     np.testing.assert_allclose(oracle_mod.forward_warp(seeded["flow"]), seeded["forward_warp"], rtol=1e-6)
+    np.testing.assert_allclose(oracle_mod.smoothness_loss(seeded["flow"], 2), float(seeded["smooth_loss_o2"]), rtol=1e-7)
+    np.testing.assert_array_equal(oracle_mod.gradient_loss_grad(seeded["im1"], seeded["image_warp"], seeded["border_mask"]),
+                                  seeded["gradient_loss_grad"])

@@ -106,3 +106,23 @@ def test_charbonnier_grad(oracle_mod):
             got = oracle_mod.charbonnier_loss_grad(x, mask, gout=1.0, beta=beta)
             num = np_ref.numeric_grad(lambda v: np_ref.charbonnier(v, mask, beta=beta), x, 1e-6)
             np.testing.assert_allclose(got, num, rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+def test_smoothness_grad(oracle_mod, order):
+    """smoothness_loss / second_order_loss gradient vs float64 central differences."""
+    rng = np.random.default_rng(12 + order)
+    flow = (rng.standard_normal((2, 6, 7, 2)) * 3).astype(np.float32)
+    g = oracle_mod.smoothness_loss_grad(flow, order)
+    num = np_ref.numeric_grad(lambda x: np_ref.smoothness_loss(x, order), flow, eps=1e-6)
+    np.testing.assert_allclose(g, num, rtol=1e-3, atol=1e-6)
+
+
+def test_gradient_loss_grad(oracle_mod):
+    rng = np.random.default_rng(14)
+    a = rng.uniform(size=(2, 6, 7, 3)).astype(np.float32)
+    b = rng.uniform(size=(2, 6, 7, 3)).astype(np.float32)
+    mask = (rng.uniform(size=(2, 6, 7, 1)) > 0.2).astype(np.float32)
+    g = oracle_mod.gradient_loss_grad(a, b, mask)
+    num = np_ref.numeric_grad(lambda x: np_ref.gradient_loss(a, x, mask), b, eps=1e-6)
+    np.testing.assert_allclose(g, num, rtol=1e-3, atol=1e-6)

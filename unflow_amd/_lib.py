@@ -42,6 +42,12 @@ SIGNATURES = {
     "unflow_fb_occlusion": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "unflow_charbonnier_fwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _LL, _P]),
     "unflow_charbonnier_bwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _LL, _P]),
+    "unflow_smoothness_loss_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _LL, _P]),
+    "unflow_smoothness_loss_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _LL, _P]),
+    "unflow_smoothness_deltas": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_gradient_loss_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _LL, _P]),
+    "unflow_gradient_loss_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _LL, _P]),
+    "unflow_gradient_delta": (_I, [_P, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

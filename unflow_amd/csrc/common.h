@@ -22,6 +22,10 @@ inline int launch_status(const char *what) {
   return UNFLOW_OK;
 }
 
+// Final pass of every loss reduction (census.hip): *loss = sum(partial[0..n)) * inv_norm,
+// one block, fixed order, double accumulation.
+int reduce_partials(const float *partial, int n, double inv_norm, float *loss, hipStream_t s);
+
 inline hipStream_t as_stream(unflow_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 inline unsigned blocks_for(long long n, int block) { return (unsigned)((n + block - 1) / block); }
@@ -29,6 +33,19 @@ inline unsigned blocks_for(long long n, int block) { return (unsigned)((n + bloc
 // Number of per-block partial sums the reductions use (fixed so the final pass
 // is one 1024-thread block and the summation order never depends on the size).
 constexpr int kReduceBlocks = 2048;
+
+// Separately rounded product / sum.  TensorFlow evaluates the reference's Python
+// graphs op by op, so `a*b + c` there is two roundings; hipcc contracts `x*y`
+// followed by `+` into an FMA by default (and HIP's __fmul_rn is a plain `x*y`),
+// so the contraction is switched off for exactly these operations.
+__device__ inline float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ inline float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 
 __device__ inline float wave_sum(float v) {
 #pragma unroll

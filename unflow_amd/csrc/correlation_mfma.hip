@@ -175,7 +175,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
                                                                     int nbx, int nby) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cx = wave & 1, ty = (wave >> 1) & 1, tx = wave >> 2;
+  // waves w and w+4 share a SIMD: they get the two tile ROWS, whose numbers of
+  // live window rows differ at the top and bottom of the image (rowmask), so that
+  // every SIMD carries the same MFMA load between two barriers
+  const int cx = wave & 1, tx = (wave >> 1) & 1, ty = wave >> 2;
   const int vb = xcd_remap(blockIdx.x, gridDim.x);
   const int bx = vb % nbx, by = (vb / nbx) % nby, bz = vb / (nbx * nby);
   const int cy = bz & 1;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   unsigned rowmask = 0;
   {
     const int wv = __builtin_amdgcn_readfirstlane(wave);
-    const int tyu = (wv >> 1) & 1;
+    const int tyu = wv >> 2;
 #pragma unroll
     for (int q = 0; q < TQ; ++q) {
       const int r0 = ys0 + tyu * TP - R + 4 * q;
@@ -218,7 +221,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the stage
 
   constexpr int GROUPS = (KC / 4) * TQ;                              // MFMA groups per chunk (12)
-  constexpr int PER_GROUP = (St::PER_WAVE + GROUPS - 1) / GROUPS;    // DMA pieces issued after each group
+  // DMA pieces issued after each group: all of them in the first half of the
+  // chunk, so that the last one has half a chunk to land before the barrier
+  constexpr int PER_GROUP = (2 * St::PER_WAVE + GROUPS - 1) / GROUPS;
   for (int ch = 0; ch < nchunks; ++ch) {
     const float *cur = lds + (ch & 1) * STAGE;
     float *nxt = lds + ((ch + 1) & 1) * STAGE;

@@ -219,10 +219,10 @@ __global__ __launch_bounds__(kBlock) void image_warp_fwd_kernel(const float *__r
       }
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        float s = __fmul_rn(wa, la[c]);
-        s = __fadd_rn(s, __fmul_rn(wb, lb[c]));
-        s = __fadd_rn(s, __fmul_rn(wc, lc[c]));
-        s = __fadd_rn(s, __fmul_rn(wd, ld[c]));
+        float s = mul_rn(wa, la[c]);
+        s = add_rn(s, mul_rn(wb, lb[c]));
+        s = add_rn(s, mul_rn(wc, lc[c]));
+        s = add_rn(s, mul_rn(wd, ld[c]));
         out[cb + c] = s;
       }
     }

@@ -1,12 +1,13 @@
-"""Hot subset of ``src/e2eflow/core/losses.py`` on the HIP kernels.
+"""``src/e2eflow/core/losses.py`` on the HIP kernels.
 
 Same function names and signatures as the reference: ``ternary_loss``
 (losses.py:90), ``charbonnier_loss`` (:298), ``create_mask`` (:325),
 ``create_border_mask`` (:338), ``create_outgoing_mask`` (:347), ``length_sq``
-(:12), ``photometric_loss`` (:198) and the part of ``compute_losses`` (:16-87)
-that feeds the census term: the four ``image_warp`` calls, the forward-backward
-occlusion masks and the two ``forward_warp`` disocclusion maps.  The smoothness
-/ gradient / diffusion terms are 3x3 TF convs outside this path.
+(:12), ``photometric_loss`` (:198), ``gradient_loss`` (:244), ``smoothness_loss``
+(:250), ``second_order_loss`` (:290), their ``_*_deltas`` helpers, and
+``compute_losses`` (:16-87) with all eight entries of its dict.  ``occlusion``
+(:125), ``divergence`` (:147) and ``diffusion_loss`` (:173) have no caller on
+the training path and are not mirrored.
 """
 import ctypes
 import math
@@ -130,6 +131,123 @@ def photometric_loss(im_diff, mask):
     return charbonnier_loss(im_diff, mask, beta=255)  # losses.py:198-199
 
 
+# --------------------------------------------------------------------------- 3x3 stencil terms
+def _deltas(flow, order):
+    flow = _dev(flow, "flow")
+    _require_rank4(flow, "flow")
+    _check_flow(None, flow)
+    B, H, W, _ = flow.shape
+    K = 2 if order == 1 else 4
+    du, dv, m = (torch.empty((B, H, W, K), device=flow.device, dtype=torch.float32) for _ in range(3))
+    with torch.cuda.device(flow.device):
+        _lib.check(_lib.load().unflow_smoothness_deltas(_ptr(flow), _ptr(du), _ptr(dv), _ptr(m), B, H, W,
+                                                        order, _stream()))
+    return du, dv, m
+
+
+def _smoothness_deltas(flow):
+    """(delta_u, delta_v, mask), each [B,H,W,2] (losses.py:206-225).  Values only (test hook);
+    the differentiable path is ``smoothness_loss``."""
+    return _deltas(flow, 1)
+
+
+def _second_order_deltas(flow):
+    """(delta_u, delta_v, mask), each [B,H,W,4] (losses.py:258-287)."""
+    return _deltas(flow, 2)
+
+
+class _SmoothnessLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow, order, norm_count):
+        flow = _dev(flow, "flow")
+        _require_rank4(flow, "flow")
+        _check_flow(None, flow)
+        B, H, W, _ = flow.shape
+        loss = torch.empty((), device=flow.device, dtype=torch.float32)
+        ws = _workspace(B * H * W, flow.device)
+        with torch.cuda.device(flow.device):
+            _lib.check(_lib.load().unflow_smoothness_loss_fwd(_ptr(flow), _ptr(loss), _ptr(ws), B, H, W,
+                                                              order, norm_count, _stream()))
+        ctx.save_for_backward(flow)
+        ctx.cfg = (order, norm_count)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        flow, = ctx.saved_tensors
+        order, norm_count = ctx.cfg
+        B, H, W, _ = flow.shape
+        gout = gout.contiguous()
+        d = torch.empty_like(flow)
+        with torch.cuda.device(flow.device):
+            _lib.check(_lib.load().unflow_smoothness_loss_bwd(_ptr(flow), _ptr(gout), _ptr(d), B, H, W,
+                                                              order, norm_count, _stream()))
+        return d, None, None
+
+
+def smoothness_loss(flow, norm_count=0):
+    """First-order smoothness (losses.py:250-255): loss_u + loss_v of the masked
+    forward differences.  ``norm_count`` (extension): 0 = B*H*W*2."""
+    return _SmoothnessLoss.apply(flow, 1, norm_count)
+
+
+def second_order_loss(flow, norm_count=0):
+    """Second-order smoothness (losses.py:290-295).  ``norm_count``: 0 = B*H*W*4."""
+    return _SmoothnessLoss.apply(flow, 2, norm_count)
+
+
+def _gradient_delta(im1, im2_warped):
+    """conv2d(im1, sobel) - conv2d(im2_warped, sobel), [B,H,W,6] (losses.py:228-241).  Values only."""
+    im1, im2_warped = _dev(im1, "im1"), _dev(im2_warped, "im2_warped")
+    _require_rank4(im1, "im1")
+    B, H, W, C = im1.shape
+    if C != 3 or im2_warped.shape != im1.shape:
+        raise ValueError("_gradient_delta expects two [B,H,W,3] images")
+    diff = torch.empty((B, H, W, 6), device=im1.device, dtype=torch.float32)
+    with torch.cuda.device(im1.device):
+        _lib.check(_lib.load().unflow_gradient_delta(_ptr(im1), _ptr(im2_warped), _ptr(diff), B, H, W,
+                                                     _stream()))
+    return diff
+
+
+class _GradientLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, im1, im2_warped, mask, norm_count):
+        im1, im2_warped, mask = _dev(im1, "im1"), _dev(im2_warped, "im2_warped"), _dev(mask, "mask")
+        _require_rank4(im1, "im1")
+        B, H, W, C = im1.shape
+        if C != 3 or im2_warped.shape != im1.shape:
+            raise ValueError("gradient_loss expects two [B,H,W,3] images, got %s and %s"
+                             % (tuple(im1.shape), tuple(im2_warped.shape)))
+        if tuple(mask.shape) != (B, H, W, 1):
+            raise ValueError("mask must have shape %s, got %s" % ((B, H, W, 1), tuple(mask.shape)))
+        loss = torch.empty((), device=im1.device, dtype=torch.float32)
+        ws = _workspace(B * H * W, im1.device)
+        with torch.cuda.device(im1.device):
+            _lib.check(_lib.load().unflow_gradient_loss_fwd(_ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss),
+                                                            _ptr(ws), B, H, W, norm_count, _stream()))
+        ctx.save_for_backward(im1, im2_warped, mask)
+        ctx.norm_count = norm_count
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        im1, im2_warped, mask = ctx.saved_tensors
+        B, H, W, _ = im1.shape
+        gout = gout.contiguous()
+        d = torch.empty_like(im2_warped)
+        with torch.cuda.device(im1.device):
+            _lib.check(_lib.load().unflow_gradient_loss_bwd(_ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(gout),
+                                                            _ptr(d), B, H, W, ctx.norm_count, _stream()))
+        return None, d, None, None
+
+
+def gradient_loss(im1, im2_warped, mask, norm_count=0):
+    """Charbonnier of the masked Sobel-gradient difference (losses.py:244-247).
+    Gradient flows into ``im2_warped`` only.  ``norm_count``: 0 = B*H*W*6."""
+    return _GradientLoss.apply(im1, im2_warped, mask, norm_count)
+
+
 # --------------------------------------------------------------------------- census
 class _TernaryLoss(torch.autograd.Function):
     @staticmethod
@@ -192,10 +310,8 @@ def ternary_dist(im1, im2_warped, max_distance=1):
 # --------------------------------------------------------------------------- composite
 def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion='',
                    data_max_distance=1, norm_batch=0, terms=None, return_aux=False):
-    """The census-feeding part of ``compute_losses`` (losses.py:16-87).
-
-    Returns the dict entries this path owns: 'ternary', 'occ', 'fb', 'photo'
-    and 'sym'.  ``terms`` (extension) restricts the dict to the named entries --
+    """``compute_losses`` (losses.py:16-87): 'sym', 'occ', 'photo', 'grad',
+    'smooth_1st', 'smooth_2nd', 'fb' and 'ternary'.  ``terms`` (extension) restricts the dict to the named entries --
     TF1 only executes the graph nodes a fetched loss needs, so a config with just
     ``ternary_weight`` never runs the others; None computes all of them.  The
     disocclusion maps (two forward_warp calls) are computed when 'sym' is asked
@@ -245,6 +361,15 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     if want('photo'):
         losses['photo'] = (charbonnier_loss(im1 - im2_warped, mask_fw, beta=255, norm_count=npx * 3) +
                            charbonnier_loss(im2 - im1_warped, mask_bw, beta=255, norm_count=npx * 3))
+    if want('grad'):
+        losses['grad'] = (gradient_loss(im1, im2_warped, mask_fw, norm_count=npx * 6) +
+                          gradient_loss(im2, im1_warped, mask_bw, norm_count=npx * 6))
+    if want('smooth_1st'):
+        losses['smooth_1st'] = (smoothness_loss(flow_fw, norm_count=npx * 2) +
+                                smoothness_loss(flow_bw, norm_count=npx * 2))
+    if want('smooth_2nd'):
+        losses['smooth_2nd'] = (second_order_loss(flow_fw, norm_count=npx * 4) +
+                                second_order_loss(flow_bw, norm_count=npx * 4))
     if want('fb'):
         losses['fb'] = (charbonnier_loss(flow_fw + flow_bw_warped, mask_fw, norm_count=npx * 2) +
                         charbonnier_loss(flow_bw + flow_fw_warped, mask_bw, norm_count=npx * 2))
