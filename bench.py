@@ -284,6 +284,20 @@ def breakdown(wl, fwd_ms, bwd_ms):
     gl = losses.gradient_loss(wl.im1, x, wl.border)
     rows.append(("gradient_loss fwd", timeit(lambda: losses.gradient_loss(wl.im1, x, wl.border)), npx * 28))
     rows.append(("gradient_loss bwd", timeit(lambda: torch.autograd.grad(gl, x, retain_graph=True)), npx * 40))
+    # the 5-level pyramid variant with the reference's [train_kitti] weights
+    from unflow_amd import unsupervised
+    kitti = dict(pyramid_loss=True, border_mask=True, mask_occlusion="fb", ternary_weight=1.0,
+                 smooth_2nd_weight=3.0, fb_weight=0.2, occ_weight=12.4)
+    g = torch.Generator(device=ffw.device)
+    g.manual_seed(7)
+    pf = [(torch.randn((B, H >> (2 + i), W >> (2 + i), 2), device=ffw.device, generator=g) * 0.3).requires_grad_(True)
+          for i in range(5)]
+    pb = [(-f.detach() + 0.02 * torch.randn(f.shape, device=ffw.device, generator=g)).requires_grad_(True) for f in pf]
+
+    def pyr():
+        loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, kitti)
+        loss.backward()
+    rows.append(("pyramid loss, 5 levels H/4..H/64, kitti weights, fwd+bwd", timeit(pyr), 0))
     rows.append(("fb_occlusion", timeit(lambda: losses.fb_occlusion(ffw, fbw)), npx * 28))
     rows.append(("downsample x2 C3", timeit(lambda: ops.downsample(wl.im1, 2)), npx * 15))
     a = torch.empty(256 * 1024 * 1024, device=ffw.device)

@@ -356,3 +356,39 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
                flow_fw_warped=flow_fw_warped, flow_diff_fw=flow_diff_fw, flow_diff_bw=flow_diff_bw,
                fb_occ_fw=fb_occ_fw, fb_occ_bw=fb_occ_bw)
     return losses, aux
+
+
+LOSSES = ['occ', 'sym', 'fb', 'grad', 'ternary', 'photo', 'smooth_1st', 'smooth_2nd']  # unsupervised.py:10
+
+
+def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params):
+    """Loss section of unsupervised_loss (core/unsupervised.py:83-145), flow pyramid given.
+    Returns (combined_loss, combined_losses)."""
+    layer_weights = [12.7, 4.35, 3.9, 3.4, 1.1]
+    layer_patch_distances = [3, 2, 2, 1, 1]
+    if params.get('full_res'):
+        layer_weights = [12.7, 5.5, 5.0, 4.35, 3.9, 3.4, 1.1]
+        layer_patch_distances = [3, 3] + layer_patch_distances
+        im1_s, im2_s, mask_s = _f32(im1_norm), _f32(im2_norm), _f32(border_mask)
+        final_flow_scale = 5.0 * 4
+    else:
+        im1_s, im2_s, mask_s = downsample(im1_norm, 4), downsample(im2_norm, 4), downsample(border_mask, 4)
+        final_flow_scale = 5.0
+    combined_losses = {k: 0.0 for k in LOSSES}
+    combined_loss = 0.0
+    pairs = list(enumerate(zip(flows_fw, flows_bw))) if params.get('pyramid_loss') \
+        else [(0, (flows_fw[0], flows_bw[0]))]
+    for n, (i, (ffw, fbw)) in enumerate(pairs):
+        flow_scale = np.float32(final_flow_scale / (2 ** i))
+        losses, _ = compute_losses(im1_s, im2_s, _f32(ffw) * flow_scale, _f32(fbw) * flow_scale,
+                                   mask_s if params.get('border_mask') else None,
+                                   params.get('mask_occlusion', ''), layer_patch_distances[i])
+        layer_loss = 0.0
+        for k in LOSSES:
+            if params.get(k + '_weight'):
+                layer_loss += params[k + '_weight'] * losses[k]
+                combined_losses[k] += layer_weights[i] * losses[k]
+        combined_loss += layer_weights[i] * layer_loss
+        if n + 1 < len(pairs):
+            im1_s, im2_s, mask_s = downsample(im1_s, 2), downsample(im2_s, 2), downsample(mask_s, 2)
+    return combined_loss, combined_losses

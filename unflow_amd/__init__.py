@@ -7,12 +7,13 @@ own op names and signatures:
 
     unflow_amd.ops         <->  src/e2eflow/ops.py
     unflow_amd.image_warp  <->  src/e2eflow/core/image_warp.py
-    unflow_amd.losses      <->  src/e2eflow/core/losses.py   (hot subset)
+    unflow_amd.losses      <->  src/e2eflow/core/losses.py
     unflow_amd.util        <->  src/e2eflow/core/util.py     (downsample dispatch)
+    unflow_amd.unsupervised <-> src/e2eflow/core/unsupervised.py:83-145 (pyramid loss)
 
 There is no CPU fallback: every op raises if ``libunflow_hip.so`` is missing or
 a tensor does not live on the GPU.
 """
 from . import _lib  # noqa: F401
 
-__all__ = ["ops", "image_warp", "losses", "util", "dist"]
+__all__ = ["ops", "image_warp", "losses", "util", "unsupervised", "dist"]
