@@ -298,6 +298,9 @@ def breakdown(wl, fwd_ms, bwd_ms):
         loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, kitti)
         loss.backward()
     rows.append(("pyramid loss, 5 levels H/4..H/64, kitti weights, fwd+bwd", timeit(pyr), 0))
+    from unflow_amd import flownet
+    flr = torch.randn((B, H // 4, W // 4, 2), device=ffw.device, generator=g) * 0.3
+    rows.append(("stacked_inputs (resize+warp+abs+concat, 14 ch)", timeit(lambda: flownet.stacked_inputs(wl.im1, wl.im2, flr)), npx * 80))
     rows.append(("fb_occlusion", timeit(lambda: losses.fb_occlusion(ffw, fbw)), npx * 28))
     rows.append(("downsample x2 C3", timeit(lambda: ops.downsample(wl.im1, 2)), npx * 15))
     a = torch.empty(256 * 1024 * 1024, device=ffw.device)

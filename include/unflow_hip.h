@@ -177,6 +177,23 @@ int unflow_gradient_loss_bwd(const float *im1, const float *im2_warped, const fl
 int unflow_gradient_delta(const float *im1, const float *im2_warped, float *diff, int B, int H, int W,
                           unflow_stream_t stream);
 
+/* ---------------------------------------------------------------- stacked-net warp block
+ * The full-resolution input block of the refinement networks
+ * (src/e2eflow/core/flownet.py:46-57):
+ *   flow = tf.image.resize_bilinear(flow_lr, [H, W]) * mult   (mult = 4 * FLOW_SCALE)
+ *   out  = concat([im1, im2, flow, image_warp(im2, flow), |warp - im1|])  [B,H,W,14]
+ * im1, im2 [B,H,W,3]; flow_lr [B,h,w,2].  Forward only: the reference stops the
+ * gradient here unless train_all is set (flownet.py:51-54); the differentiable
+ * form is composed from unflow_resize_bilinear_* and unflow_image_warp_*. */
+int unflow_stacked_inputs_fwd(const float *im1, const float *im2, const float *flow_lr, float *out,
+                              int B, int H, int W, int h, int w, float mult, unflow_stream_t stream);
+/* tf.image.resize_bilinear (TF 1.x, align_corners=False) times mult: in [B,h,w,C] ->
+ * out [B,H,W,C]; _bwd: gin [B,h,w,C] overwritten with the gradient wrt in. */
+int unflow_resize_bilinear_fwd(const float *in, float *out, int B, int h, int w, int H, int W, int C,
+                               float mult, unflow_stream_t stream);
+int unflow_resize_bilinear_bwd(const float *gout, float *gin, int B, int h, int w, int H, int W, int C,
+                               float mult, unflow_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

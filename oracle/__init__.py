@@ -358,6 +358,35 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     return losses, aux
 
 
+# --------------------------------------------------------------------------- stacked-net warp block
+def resize_bilinear(x, height, width, mult=1.0):
+    """tf.image.resize_bilinear (TF 1.x, align_corners=False) times ``mult``."""
+    x = _f32(x)
+    B, h, w, C = x.shape
+    out = np.empty((B, height, width, C), np.float32)
+    lib().oracle_resize_bilinear_fwd(_p(x), _p(out), B, h, w, height, width, C, ctypes.c_float(mult))
+    return out
+
+
+def resize_bilinear_grad(gout, h, w, mult=1.0):
+    gout = _f32(gout)
+    B, H, W, C = gout.shape
+    gin = np.empty((B, h, w, C), np.float32)
+    lib().oracle_resize_bilinear_bwd(_p(gout), _p(gin), B, h, w, H, W, C, ctypes.c_float(mult))
+    return gin
+
+
+def stacked_inputs(im1, im2, flow_lr, mult=20.0):
+    """flownet.py:46-57: concat([im1, im2, flow, warp, |warp - im1|]) with
+    flow = resize_bilinear(flow_lr) * 4 * FLOW_SCALE."""
+    im1, im2, flow_lr = _f32(im1), _f32(im2), _f32(flow_lr)
+    B, H, W, _ = im1.shape
+    _, h, w, _ = flow_lr.shape
+    out = np.empty((B, H, W, 14), np.float32)
+    lib().oracle_stacked_inputs(_p(im1), _p(im2), _p(flow_lr), _p(out), B, H, W, h, w, ctypes.c_float(mult))
+    return out
+
+
 LOSSES = ['occ', 'sym', 'fb', 'grad', 'ternary', 'photo', 'smooth_1st', 'smooth_2nd']  # unsupervised.py:10
 
 

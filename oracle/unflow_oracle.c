@@ -25,6 +25,10 @@
  *                             smoothness_loss / second_order_loss)
  *   oracle_gradient_*         src/e2eflow/core/losses.py:228-247
  *                             (_gradient_delta, gradient_loss)
+ *   oracle_stacked_inputs     src/e2eflow/core/flownet.py:46-57 (resize_bilinear
+ *                             -> image_warp -> abs -> concat); tf.image.resize_bilinear
+ *                             itself is third-party: TF 1.x align_corners=False
+ *                             semantics restated (assumption A2, PARITY UNPINNED)
  *   oracle_create_*_mask      src/e2eflow/core/losses.py:325-366
  *   oracle_fb_occlusion       src/e2eflow/core/losses.py:38-51
  *
@@ -1039,4 +1043,92 @@ void oracle_gradient_loss_bwd(const float *im1, const float *im2_warped, const f
             }
         }
   free(diff); free(gd); free(m6);
+}
+
+/* ---------------------------------------------------------------------------
+ * tf.image.resize_bilinear, TensorFlow 1.x, align_corners=False (third-party;
+ * its published algorithm: scale = in/out in float, in = out_index*scale,
+ * lower = floor(in), upper = min(lower+1, in_size-1), lerp = in - lower,
+ * top = tl + (tr-tl)*x_lerp, bottom likewise, out = top + (bottom-top)*y_lerp),
+ * followed by the reference's `* 4 * FLOW_SCALE` (flownet.py:48) as `mult`.
+ * ------------------------------------------------------------------------- */
+void oracle_resize_bilinear_fwd(const float *in, float *out, int B, int h, int w, int H, int W, int C,
+                                float mult) {
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  for (int b = 0; b < B; b++)
+    for (int y = 0; y < H; y++) {
+      const float iy = (float)y * sh;
+      const float fy = floorf(iy);
+      int y0 = (int)fy; if (y0 > h - 1) y0 = h - 1;
+      const int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+      const float ly = iy - fy;
+      for (int x = 0; x < W; x++) {
+        const float ix = (float)x * sw;
+        const float fx = floorf(ix);
+        int x0 = (int)fx; if (x0 > w - 1) x0 = w - 1;
+        const int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+        const float lx = ix - fx;
+        for (int c = 0; c < C; c++) {
+          const float tl = in[(((size_t)b * h + y0) * w + x0) * C + c], tr = in[(((size_t)b * h + y0) * w + x1) * C + c];
+          const float bl = in[(((size_t)b * h + y1) * w + x0) * C + c], br = in[(((size_t)b * h + y1) * w + x1) * C + c];
+          const float top = tl + (tr - tl) * lx;
+          const float bot = bl + (br - bl) * lx;
+          out[(((size_t)b * H + y) * W + x) * C + c] = (top + (bot - top) * ly) * mult;
+        }
+      }
+    }
+}
+
+/* gradient of the above wrt `in` (double accumulation, then rounded) */
+void oracle_resize_bilinear_bwd(const float *gout, float *gin, int B, int h, int w, int H, int W, int C,
+                                float mult) {
+  const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+  double *acc = (double *)calloc((size_t)B * h * w * C, sizeof(double));
+  for (int b = 0; b < B; b++)
+    for (int y = 0; y < H; y++) {
+      const float iy = (float)y * sh;
+      const float fy = floorf(iy);
+      int y0 = (int)fy; if (y0 > h - 1) y0 = h - 1;
+      const int y1 = y0 + 1 < h ? y0 + 1 : h - 1;
+      const double ly = iy - fy;
+      for (int x = 0; x < W; x++) {
+        const float ix = (float)x * sw;
+        const float fx = floorf(ix);
+        int x0 = (int)fx; if (x0 > w - 1) x0 = w - 1;
+        const int x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+        const double lx = ix - fx;
+        for (int c = 0; c < C; c++) {
+          const double g = (double)gout[(((size_t)b * H + y) * W + x) * C + c] * mult;
+          acc[(((size_t)b * h + y0) * w + x0) * C + c] += g * (1 - ly) * (1 - lx);
+          acc[(((size_t)b * h + y0) * w + x1) * C + c] += g * (1 - ly) * lx;
+          acc[(((size_t)b * h + y1) * w + x0) * C + c] += g * ly * (1 - lx);
+          acc[(((size_t)b * h + y1) * w + x1) * C + c] += g * ly * lx;
+        }
+      }
+    }
+  for (size_t i = 0; i < (size_t)B * h * w * C; i++) gin[i] = (float)acc[i];
+  free(acc);
+}
+
+/* flownet.py:46-57: inputs = concat([im1, im2, flow, warp, diff]) -> [B,H,W,14] */
+void oracle_stacked_inputs(const float *im1, const float *im2, const float *flow_lr, float *out, int B, int H,
+                           int W, int h, int w, float mult) {
+  const size_t npix = (size_t)B * H * W;
+  float *flow = (float *)malloc(npix * 2 * sizeof(float));
+  float *warp = (float *)malloc(npix * 3 * sizeof(float));
+  oracle_resize_bilinear_fwd(flow_lr, flow, B, h, w, H, W, 2, mult);
+  oracle_image_warp_fwd(im2, flow, warp, B, H, W, 3);
+  for (size_t p = 0; p < npix; p++) {
+    float *o = out + p * 14;
+    for (int c = 0; c < 3; c++) {
+      o[c] = im1[p * 3 + c];
+      o[3 + c] = im2[p * 3 + c];
+      o[8 + c] = warp[p * 3 + c];
+      o[11 + c] = fabsf(warp[p * 3 + c] - im1[p * 3 + c]);
+    }
+    o[6] = flow[p * 2];
+    o[7] = flow[p * 2 + 1];
+  }
+  free(flow);
+  free(warp);
 }

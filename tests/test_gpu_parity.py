@@ -428,6 +428,41 @@ def test_pyramid_loss_vs_oracle(oracle_mod, dev, full_res, pyramid):
         close(f0.grad, wantg, 1e-3, 1e-4 * np.abs(wantg).max())
 
 
+@pytest.mark.parametrize("B,H,W,h,w", [(2, 64, 96, 16, 24), (1, 37, 53, 10, 14), (3, 8, 8, 2, 2), (1, 5, 300, 5, 75)])
+def test_stacked_inputs_vs_oracle(oracle_mod, dev, B, H, W, h, w):
+    """flownet.py:46-57: fused block == composed block (bitwise) == oracle (1e-5)."""
+    from unflow_amd import flownet
+    rng = np.random.default_rng(B * 100 + H)
+    im1 = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+    im2 = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+    flow = (rng.standard_normal((B, h, w, 2)) * 0.3).astype(np.float32)
+    want = oracle_mod.stacked_inputs(im1, im2, flow)
+    fused = flownet.stacked_inputs(T(im1, dev), T(im2, dev), T(flow, dev))
+    assert fused.shape == (B, H, W, 14)
+    close(fused, want, 1e-5, 1e-5)
+    np.testing.assert_array_equal(N(fused[..., 6:8]), want[..., 6:8])        # the resized flow is bit-exact
+    f = T(flow, dev).requires_grad_(True)
+    comp = flownet.stacked_inputs(T(im1, dev), T(im2, dev), f, train_all=True)
+    np.testing.assert_array_equal(N(comp), N(fused))
+    # train_all: gradient reaches the low-resolution flow through warp and diff
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    (comp * T(g, dev)).sum().backward()
+    full = want[..., 6:8]
+    warp = want[..., 8:11]
+    g_warp = g[..., 8:11] + g[..., 11:14] * np.sign(warp - im1)
+    _, g_full = oracle_mod.image_warp_grad(g_warp, im2, full, want_im=False)
+    wantg = oracle_mod.resize_bilinear_grad(g_full + g[..., 6:8], h, w, mult=20.0)
+    close(f.grad, wantg, 1e-3, 1e-4 * np.abs(wantg).max())
+
+
+def test_resize_bilinear_vs_oracle(oracle_mod, dev):
+    from unflow_amd import flownet
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 6, 9, 3)).astype(np.float32)
+    for size in ((6, 9), (24, 36), (13, 20), (3, 4)):
+        np.testing.assert_array_equal(N(flownet.resize_bilinear(T(x, dev), size)), oracle_mod.resize_bilinear(x, *size))
+
+
 def test_empty_inputs(dev):
     from unflow_amd import ops
     from unflow_amd.image_warp import image_warp

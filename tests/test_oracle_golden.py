@@ -189,6 +189,29 @@ def test_stencil_terms_match_numpy(oracle_mod):
     assert m[0, :, :, 2].sum() == 7 * 9 and m[0, :, :, 0].sum() == 9 * 9 and m[0, :, :, 1].sum() == 7 * 11
 
 
+def test_resize_bilinear_and_stacked_inputs(oracle_mod):
+    """tf.image.resize_bilinear (TF 1.x legacy semantics, assumption A2) restated; flownet.py:46-57."""
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 5, 7, 2)).astype(np.float32)
+    np.testing.assert_array_equal(oracle_mod.resize_bilinear(x, 5, 7), x)            # identity at scale 1
+    up = oracle_mod.resize_bilinear(x, 20, 28)
+    np.testing.assert_array_equal(up[:, ::4, ::4], x)                                 # integer positions hit the samples
+    np.testing.assert_allclose(up[:, 2, 0], 0.5 * (x[:, 0, 0] + x[:, 1, 0]), rtol=1e-6, atol=1e-6)
+    np.testing.assert_array_equal(up[:, 17:, :], np.broadcast_to(up[:, 16:17, :], up[:, 17:, :].shape))  # clamped last row
+    const = np.full((1, 3, 4, 2), 1.25, np.float32)
+    np.testing.assert_array_equal(oracle_mod.resize_bilinear(const, 12, 16, mult=20.0), np.full((1, 12, 16, 2), 25.0))
+    # adjoint identity of the gradient
+    g = rng.standard_normal(up.shape).astype(np.float32)
+    gi = oracle_mod.resize_bilinear_grad(g, 5, 7)
+    np.testing.assert_allclose((up.astype(np.float64) * g).sum(), (x.astype(np.float64) * gi).sum(), rtol=1e-5)
+    im1 = rng.uniform(size=(2, 20, 28, 3)).astype(np.float32)
+    im2 = rng.uniform(size=(2, 20, 28, 3)).astype(np.float32)
+    out = oracle_mod.stacked_inputs(im1, im2, x * 0.1)
+    flow = oracle_mod.resize_bilinear(x * 0.1, 20, 28, mult=20.0)
+    warp = oracle_mod.image_warp(im2, flow)
+    np.testing.assert_array_equal(out, np.concatenate([im1, im2, flow, warp, np.abs(warp - im1)], 3))
+
+
 def test_seeded_fixture_is_reproducible(seeded, oracle_mod):
     """The committed oracle outputs are what the oracle computes today."""
     c, p0, p1 = oracle_mod.correlation(seeded["corr_f0"], seeded["corr_f1"])
