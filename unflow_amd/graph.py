@@ -1,0 +1,31 @@
+"""HIP-graph capture of a launch-bound sequence of ops.
+
+Every entry point of ``libunflow_hip.so`` takes the stream explicitly, allocates
+nothing and never synchronises, so a whole loss pyramid (about 350 small
+launches at the coarse levels) can be recorded once on a capture stream and
+replayed as one graph launch: 5.0 ms -> 2.1 ms for the 5-level KITTI pyramid at
+B=32 (tools/graph_pyramid.py).  The reference gets the same effect from the TF1
+executor running a static graph; this is its MI355X counterpart.
+"""
+import torch
+
+
+class GraphedStep:
+    """Capture ``fn()`` (which reads fixed input tensors and returns tensors) into a
+    HIP graph.  ``replay()`` re-runs it on the current contents of those inputs and
+    returns the same output tensors, overwritten in place."""
+
+    def __init__(self, fn, warmup=2):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):          # warm-up off the default stream, as capture requires
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.outputs = fn()
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs
