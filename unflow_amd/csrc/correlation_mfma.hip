@@ -349,6 +349,261 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
 }
 
 // ===========================================================================
+// Forward, two workgroups per CU.  The kernel above holds 36 accumulator tiles
+// per wave (256 VGPRs, one 8-wave workgroup per CU): whenever that workgroup waits
+// at a barrier or writes its epilogue the matrix pipe idles (44 % of its time,
+// cycle stamps in DESIGN.md).  Here a workgroup computes only HALF of the window
+// rows of a region (N-tile rows 3h .. 3h+2): 18 accumulator tiles per wave, 128
+// VGPRs, 16 of the 28 window rows staged (64.5 KB of LDS), so two independent
+// workgroups share a CU and one's barriers and epilogue hide behind the other's
+// MFMAs.  The two halves of a region write disjoint 64-byte output segments:
+// element (position row py, displacement row dy') belongs to the half that holds
+// window row py + dy' (>= 12: upper half).  DMA volume 16/14 of the kernel above.
+// ===========================================================================
+constexpr int TQH = TQ / 2;                    // 3 N-tile rows per workgroup
+constexpr int NTH = TQH * TQ;                  // 18 accumulator tiles per wave
+constexpr int LHH = RY + 4 * TQH - 4;          // 16 staged window rows
+constexpr int PLANEH = LHH * ROWF;             // 896
+constexpr int PLSH = PLANEH + 4;               // 900 = 4 mod 32 like PLS
+constexpr int F1_STAGEH = (KC * PLSH + 1 + 63) / 64 * 64;   // 7232
+constexpr int STAGEH = F1_STAGEH + F0_STAGE;   // 8256 floats = 32.25 KB
+constexpr int SLAB_DYH = 6;                    // displacement rows per epilogue slab
+constexpr int SLABH = SLAB_DYH * GW * RY * RW; // 16128 floats
+static_assert(SLABH <= 2 * STAGEH, "epilogue slab must fit the staging buffers");
+static_assert(PLSH % 32 == PLS % 32, "same bank pattern as the full-window image");
+
+template <int VEC>
+struct FwdStagerH {
+  static constexpr int PIECE = 64 * VEC;
+  static constexpr int F1_PER_WAVE = (PLANEH + PIECE - 1) / PIECE;       // 4 (dwordx4, last one half) or 14
+  static constexpr int F0_PIECES = F0_STAGE / PIECE;
+  static constexpr int F0_PER_WAVE = (F0_PIECES + NWAVES - 1) / NWAVES;
+  static constexpr int PER_WAVE = F1_PER_WAVE + F0_PER_WAVE;
+
+  unsigned voff[PER_WAVE];
+  int wave;
+  __amdgpu_buffer_rsrc_t r0, r1;
+
+  // wrow0: first staged window row, relative to the region's window (0 or 12)
+  __device__ inline void init(int H, int W, int cy, int ys0, int xs0, int wrow0) {
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __builtin_assume(wave >= 0 && wave < NWAVES);
+    const int lane = threadIdx.x & 63;
+    const long long plane = (long long)H * W;
+#pragma unroll
+    for (int j = 0; j < F1_PER_WAVE; ++j) {
+      const int f = (j * 64 + lane) * VEC;
+      const int row = f / ROWF, x = f - row * ROWF;
+      const int Y = S * (ys0 - R + wrow0 + row) + cy, X = S * (xs0 - R) + x;
+      const bool in = f < PLANEH && Y >= 0 && Y < H && X >= 0 && X < W;
+      voff[j] = in ? (unsigned)((wave * plane + (long long)Y * W + X) * 4) : OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < F0_PER_WAVE; ++j) {
+      const int p = wave + NWAVES * j;
+      const int f = (p * 64 + lane) * VEC;
+      const int c = f / F0PL, r = f - c * F0PL, row = r / RW, x = r - row * RW;
+      const int Y = S * (ys0 + row) + cy, X = S * xs0 + x;
+      const bool in = p < F0_PIECES && Y >= 0 && Y < H && X >= 0 && X < W;
+      voff[F1_PER_WAVE + j] = in ? (unsigned)((c * plane + (long long)Y * W + X) * 4) : OOB;
+    }
+  }
+  __device__ inline void bind(const float *in0, const float *in1, long long item, int c0, int C, long long plane) {
+    const unsigned bytes = (unsigned)((long long)(C - c0) * plane * 4);
+    r0 = make_rsrc(in0 + (item * C + c0) * plane, bytes);
+    r1 = make_rsrc(in1 + (item * C + c0) * plane, bytes);
+  }
+  template <int J>
+  __device__ inline void issue_one(float *stage) const {
+    if constexpr (J < F1_PER_WAVE) {
+      __builtin_assume(wave >= 0 && wave < NWAVES);
+      float *dst = stage + wave * PLSH + (wave & 1) + J * PIECE;
+      if constexpr ((J + 1) * PIECE <= PLANEH) {
+        dma<VEC>(r1, dst, voff[J], 0);
+      } else {
+        if ((int)((J * 64 + (threadIdx.x & 63)) * VEC) < PLANEH) dma<VEC>(r1, dst, voff[J], 0);
+      }
+    } else if constexpr (J < PER_WAVE) {
+      __builtin_assume(wave >= 0 && wave < NWAVES);
+      const int p = wave + NWAVES * (J - F1_PER_WAVE);
+      if (p < F0_PIECES) dma<VEC>(r0, stage + F1_STAGEH + p * PIECE, voff[J], 0);
+    }
+  }
+  template <int J0, int N>
+  __device__ inline void issue_range(float *stage) const {
+    if constexpr (N > 0) {
+      issue_one<J0>(stage);
+      issue_range<J0 + 1, N - 1>(stage);
+    }
+  }
+};
+
+template <int VEC>
+__global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(const float *__restrict__ in0,
+                                                                         const float *__restrict__ in1,
+                                                                         float *__restrict__ out, int C, int H,
+                                                                         int W, int nbx, int nby) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cx = wave & 1, tx = (wave >> 1) & 1, ty = wave >> 2;
+  int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int half = vb & 1;                     // uniform: which three N-tile rows
+  vb >>= 1;
+  const int bx = vb % nbx, by = (vb / nbx) % nby, bz = vb / (nbx * nby);
+  const int cy = bz & 1;
+  const long long item = bz >> 1;
+  const int ys0 = by * RY, xs0 = bx * RX;
+  const int hs = (H - cy + S - 1) / S;
+  if (ys0 >= hs) return;
+
+  f32x4 acc[NTH];
+#pragma unroll
+  for (int t = 0; t < NTH; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int k = lane >> 4, n = lane & 15;
+  const int a_off = F1_STAGEH + k * F0PL + (ty * TP + (n >> 2)) * RW + S * (tx * TP + (n & 3)) + cx;
+  const int b_off = k * PLSH + (k & 1) + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + cx;
+
+  unsigned rowmask = 0;
+  {
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int tyu = wv >> 2;
+#pragma unroll
+    for (int q = 0; q < TQH; ++q) {
+      const int r0 = ys0 + tyu * TP - R + 4 * (TQH * half + q);
+      if (r0 + 3 >= 0 && r0 < hs) rowmask |= 1u << q;
+    }
+  }
+
+  using St = FwdStagerH<VEC>;
+  St st;
+  st.init(H, W, cy, ys0, xs0, 4 * TQH * half);
+  const long long plane = (long long)H * W;
+  const int nchunks = (C + KC - 1) / KC;
+  st.bind(in0, in1, item, 0, C, plane);
+  st.template issue_range<0, St::PER_WAVE>(lds);
+  __syncthreads();
+
+  constexpr int GROUPS = (KC / 4) * TQH;                             // 6 MFMA groups per chunk
+  constexpr int PER_GROUP = (2 * St::PER_WAVE + GROUPS - 1) / GROUPS; // all DMA in the first K-step
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const float *cur = lds + (ch & 1) * STAGEH;
+    float *nxt = lds + ((ch + 1) & 1) * STAGEH;
+    const bool more = ch + 1 < nchunks;
+    if (more) st.bind(in0, in1, item, (ch + 1) * KC, C, plane);
+#pragma unroll
+    for (int kk = 0; kk < KC / 4; ++kk) {
+      const float a = cur[a_off + kk * 4 * F0PL];
+      const float *bp = cur + b_off + kk * 4 * PLSH;
+      float b[NTH];
+#pragma unroll
+      for (int t = 0; t < NTH; ++t) b[t] = bp[(t / TQ) * 4 * ROWF + (t % TQ) * 4 * S];
+      __builtin_amdgcn_sched_barrier(0);
+      auto group = [&](auto G) {
+        constexpr int g = decltype(G)::value;
+        if (rowmask & (1u << g)) {
+#pragma unroll
+          for (int t = g * TQ; t < (g + 1) * TQ; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
+        }
+        if (more) {
+          if (kk == 0) st.template issue_range<g * PER_GROUP, PER_GROUP>(nxt);
+          else st.template issue_range<(TQH + g) * PER_GROUP, PER_GROUP>(nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      group(Int<0>{}); group(Int<1>{}); group(Int<2>{});
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue (see the full-window kernel): two slabs of 6 displacement rows,
+  // dy' = 9*half + 6*s + ddl; local tile row tl holds dy' = 4*(3*half + tl) + u.
+  const float scale = 1.f / (float)C;
+  const bool pow2 = (C & (C - 1)) == 0;
+  const int py = lane >> 4;
+  const int row = ty * TP + py;
+  const int D = GW * GW;
+  float *ob = lds;
+  const int u = (n >> 2) - py, bq = n & 3;
+  int L[4];
+  bool mx_first[4], mx_last[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    L[j] = (row * RW + S * (tx * TP + j) + cx) * (SLAB_DYH * GW) + u * GW + (bq - j);
+    mx_first[j] = bq >= j;
+    mx_last[j] = bq <= j;
+  }
+  auto epilogue = [&](auto HALF) {
+    constexpr int hf = decltype(HALF)::value;
+    auto scatter = [&](auto SLABNO, auto DIVIDE) {
+      constexpr int s = decltype(SLABNO)::value;
+      constexpr bool divide = decltype(DIVIDE)::value;
+      constexpr int base = 9 * hf + SLAB_DYH * s;
+#pragma unroll
+      for (int tl = 0; tl < TQH; ++tl) {
+        constexpr int dlo = base, dhi = (base + SLAB_DYH - 1) < 2 * R ? (base + SLAB_DYH - 1) : 2 * R;
+        const int tqy = TQH * hf + tl;
+        const int lo = dlo - 4 * tqy, hi = dhi - 4 * tqy;
+        if (hi < -3 || lo > 3) continue;
+        const bool my = u >= lo && u <= hi;
+#pragma unroll
+        for (int tqx = 0; tqx < TQ; ++tqx) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = my && (tqx == 0 ? mx_first[j] : (tqx == TQ - 1 ? mx_last[j] : true));
+            if (ok) {
+              const float v = acc[tl * TQ + tqx][j];
+              ob[L[j] + (4 * tqy - base) * GW + 4 * tqx] = divide ? v / (float)C : v * scale;
+            }
+          }
+        }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (pow2) {
+        if (s == 0) scatter(Int<0>{}, std::false_type{});
+        else scatter(Int<1>{}, std::false_type{});
+      } else {
+        if (s == 0) scatter(Int<0>{}, std::true_type{});
+        else scatter(Int<1>{}, std::true_type{});
+      }
+      __syncthreads();
+      const int base = 9 * hf + SLAB_DYH * s;
+      for (int idx = threadIdx.x; idx < SLABH / 4; idx += NTHREADS) {
+        const int c4 = idx % (RW / 4);
+        int rest = idx / (RW / 4);
+        const int r = rest % RY;
+        rest /= RY;
+        const int dxx = rest % GW, ddl = rest / GW;
+        const int dyp = base + ddl;
+        // this half owns (row, dy') iff the window row (r & 3) + dy' lies in its three tile rows
+        if (dyp > 2 * R || (((r & 3) + dyp >= 4 * TQH) != (hf == 1))) continue;
+        const int d = dyp * GW + dxx;
+        const int y = S * (ys0 + r) + cy;
+        const int x = S * xs0 + c4 * 4;
+        if (y >= H || x >= W) continue;
+        const float *src = ob + (r * RW + c4 * 4) * (SLAB_DYH * GW) + ddl * GW + dxx;
+        const float4 v = make_float4(src[0], src[SLAB_DYH * GW], src[2 * SLAB_DYH * GW], src[3 * SLAB_DYH * GW]);
+        float *dst = out + (item * D + d) * plane + (long long)y * W + x;
+        if (x + 3 < W && (W & 3) == 0) {
+          *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+          dst[0] = v.x;
+          if (x + 1 < W) dst[1] = v.y;
+          if (x + 2 < W) dst[2] = v.z;
+          if (x + 3 < W) dst[3] = v.w;
+        }
+      }
+      __syncthreads();
+    }
+  };
+  if (half == 0) epilogue(Int<0>{});
+  else epilogue(Int<1>{});
+}
+
+// ===========================================================================
 // Backward.  Both gradients are the same GEMM with the roles swapped:
 //   g0[c, o] = 1/C * sum_{w in window(o)} top[d = w - o, o] * f1[c, w]
 //   g1[c, o] = 1/C * sum_{w in window(o)} top[d = o - w, w] * f0[c, w]
@@ -667,13 +922,16 @@ int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, 
   const size_t smem = sizeof(float) * 2 * STAGE;
   // 16-byte DMA segments need 16-byte aligned rows
   const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1);
-  if (wide) {
-    if (int rc = reserve_lds<corr_mfma_fwd_kernel<4>>(smem, "correlation_fwd (mfma)")) return rc;
-    hipLaunchKernelGGL(corr_mfma_fwd_kernel<4>, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby);
-  } else {
-    if (int rc = reserve_lds<corr_mfma_fwd_kernel<1>>(smem, "correlation_fwd (mfma)")) return rc;
-    hipLaunchKernelGGL(corr_mfma_fwd_kernel<1>, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby);
+  if (wide) {   // two half-window workgroups per region, two workgroups per CU: 0.76 -> 0.66 ms at B=32
+    const size_t smem2 = sizeof(float) * 2 * STAGEH;
+    if (int rc = reserve_lds<corr_mfma_fwd_half_kernel<4>>(smem2, "correlation_fwd (mfma, half windows)")) return rc;
+    hipLaunchKernelGGL(corr_mfma_fwd_half_kernel<4>, dim3(grid.x * 2), dim3(NTHREADS), smem2, s, in0, in1, out, C, H, W,
+                       nbx, nby);
+    return launch_status("correlation_fwd (mfma, half windows)");
   }
+  // rows that are not 16-byte aligned: 4-byte DMA, full-window workgroups
+  if (int rc = reserve_lds<corr_mfma_fwd_kernel<1>>(smem, "correlation_fwd (mfma)")) return rc;
+  hipLaunchKernelGGL(corr_mfma_fwd_kernel<1>, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby);
   return launch_status("correlation_fwd (mfma)");
 }
 
