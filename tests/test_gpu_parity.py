@@ -273,7 +273,11 @@ def test_forward_warp_zero_flow_analytic(dev):
     np.testing.assert_allclose(out[0, 0, 0, 0], 3.0740974, rtol=1e-6)
 
 
-@pytest.mark.parametrize("B,H,W,r", [(2, 37, 53, 3), (1, 16, 16, 1), (2, 24, 40, 2), (1, 9, 70, 3), (1, 20, 20, 4)])
+# r = 2, 3 run the pair-symmetric kernels (58- or 60-column x 64/32-row workgroup tiles): sizes
+# below, at and across those tile borders, single rows / columns, an image smaller than the window
+@pytest.mark.parametrize("B,H,W,r", [(2, 37, 53, 3), (1, 16, 16, 1), (2, 24, 40, 2), (1, 9, 70, 3), (1, 20, 20, 4),
+                                     (1, 70, 130, 3), (2, 64, 58, 3), (1, 65, 59, 3), (1, 33, 121, 2),
+                                     (1, 1, 200, 3), (1, 100, 1, 3), (1, 2, 2, 3), (3, 5, 4, 2)])
 def test_census_vs_oracle(oracle_mod, dev, B, H, W, r):
     from unflow_amd import losses
     rng = np.random.default_rng(B * 100 + W)
