@@ -126,7 +126,7 @@ def cpu_baseline(n_pairs=2):
     for a, b in ((f0, f1), (f1, f0)):
         c, p0, p1 = oracle.correlation(a, b)
         oracle.correlation_grad(top, a, b, p0, p1)
-    _, aux = oracle.compute_losses(im1, im2, ffw, fbw, border, "fb", 3)
+    _, aux = oracle.compute_losses(im1, im2, ffw, fbw, border, "fb", 3, terms=("ternary", "sym"))
     g2 = oracle.ternary_loss_grad(im1, aux["im2_warped"], aux["mask_fw"], 3)
     oracle.image_warp_grad(g2, im2, ffw, want_im=False)
     g1 = oracle.ternary_loss_grad(im2, aux["im1_warped"], aux["mask_bw"], 3)

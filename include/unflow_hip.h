@@ -177,6 +177,20 @@ int unflow_gradient_loss_bwd(const float *im1, const float *im2_warped, const fl
 int unflow_gradient_delta(const float *im1, const float *im2_warped, float *diff, int B, int H, int W,
                           unflow_stream_t stream);
 
+/* ---------------------------------------------------------------- integer census (extension)
+ * NOT in the reference (its census is the soft one above).  Classical ternary
+ * census on I = 255*gray(im), window (2*max_distance+1)^2, zero padding:
+ * signature [B,H,W,2] uint64 -- bit k of word 0: neighbour k (row-major, centre
+ * skipped) brighter than the centre by more than eps; word 1: darker by more than
+ * eps.  max_distance in [1,3].  Hamming: dist [B,H,W] int32 = number of neighbours
+ * whose ternary digit differs, total = sum of dist where mask != 0 (mask NULL = all);
+ * dist or total may be NULL.  Bit-exact against the CPU oracle. */
+int unflow_census_transform(const float *im, unsigned long long *signature, int B, int H, int W,
+                            int max_distance, float eps, unflow_stream_t stream);
+int unflow_census_hamming(const unsigned long long *sig1, const unsigned long long *sig2,
+                          const float *mask, int *dist, unsigned long long *total, int B, int H, int W,
+                          unflow_stream_t stream);
+
 /* ---------------------------------------------------------------- stacked-net warp block
  * The full-resolution input block of the refinement networks
  * (src/e2eflow/core/flownet.py:46-57):

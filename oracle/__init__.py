@@ -46,6 +46,8 @@ def lib():
         L.oracle_ternary_loss_fwd.restype = ctypes.c_double
         L.oracle_smoothness_loss_fwd.restype = ctypes.c_double
         L.oracle_gradient_loss_fwd.restype = ctypes.c_double
+        L.oracle_census_hamming.restype = ctypes.c_uint64
+        L.oracle_census_hamming.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long]
         L.oracle_num_threads.restype = ctypes.c_int
         L.oracle_border_size.restype = ctypes.c_int
         L.oracle_border_size.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_float]
@@ -316,8 +318,9 @@ DISOCC_THRESH = 0.8  # losses.py:9
 
 
 def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion="",
-                   data_max_distance=1):
-    """compute_losses (losses.py:16-87), all eight entries.  Returns (losses, aux)."""
+                   data_max_distance=1, terms=None):
+    """compute_losses (losses.py:16-87), all eight entries (or only ``terms``, as the TF1
+    executor only runs what a fetched scalar needs).  Returns (losses, aux)."""
     im2_warped = image_warp(im2, flow_fw)
     im1_warped = image_warp(im1, flow_bw)
     disocc_fw = (forward_warp(flow_fw) < DISOCC_THRESH).astype(np.float32)
@@ -339,23 +342,46 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
         mask_fw = mask_fw * (1 - disocc_bw)
         mask_bw = mask_bw * (1 - disocc_fw)
     occ_fw, occ_bw = 1 - mask_fw, 1 - mask_bw
-    losses = {
-        "sym": charbonnier_loss(occ_fw - disocc_bw) + charbonnier_loss(occ_bw - disocc_fw),
-        "occ": charbonnier_loss(occ_fw) + charbonnier_loss(occ_bw),
-        "photo": charbonnier_loss(_f32(im1) - im2_warped, mask_fw, beta=255) +
-                 charbonnier_loss(_f32(im2) - im1_warped, mask_bw, beta=255),
-        "grad": gradient_loss(im1, im2_warped, mask_fw) + gradient_loss(im2, im1_warped, mask_bw),
-        "smooth_1st": smoothness_loss(flow_fw, 1) + smoothness_loss(flow_bw, 1),
-        "smooth_2nd": smoothness_loss(flow_fw, 2) + smoothness_loss(flow_bw, 2),
-        "fb": charbonnier_loss(flow_diff_fw, mask_fw) + charbonnier_loss(flow_diff_bw, mask_bw),
-        "ternary": ternary_loss(im1, im2_warped, mask_fw, data_max_distance) +
-                   ternary_loss(im2, im1_warped, mask_bw, data_max_distance),
+    table = {
+        "sym": lambda: charbonnier_loss(occ_fw - disocc_bw) + charbonnier_loss(occ_bw - disocc_fw),
+        "occ": lambda: charbonnier_loss(occ_fw) + charbonnier_loss(occ_bw),
+        "photo": lambda: charbonnier_loss(_f32(im1) - im2_warped, mask_fw, beta=255) +
+        charbonnier_loss(_f32(im2) - im1_warped, mask_bw, beta=255),
+        "grad": lambda: gradient_loss(im1, im2_warped, mask_fw) + gradient_loss(im2, im1_warped, mask_bw),
+        "smooth_1st": lambda: smoothness_loss(flow_fw, 1) + smoothness_loss(flow_bw, 1),
+        "smooth_2nd": lambda: smoothness_loss(flow_fw, 2) + smoothness_loss(flow_bw, 2),
+        "fb": lambda: charbonnier_loss(flow_diff_fw, mask_fw) + charbonnier_loss(flow_diff_bw, mask_bw),
+        "ternary": lambda: ternary_loss(im1, im2_warped, mask_fw, data_max_distance) +
+        ternary_loss(im2, im1_warped, mask_bw, data_max_distance),
     }
+    losses = {k: fn() for k, fn in table.items() if terms is None or k in terms}
     aux = dict(im2_warped=im2_warped, im1_warped=im1_warped, mask_fw=mask_fw, mask_bw=mask_bw,
                disocc_fw=disocc_fw, disocc_bw=disocc_bw, flow_bw_warped=flow_bw_warped,
                flow_fw_warped=flow_fw_warped, flow_diff_fw=flow_diff_fw, flow_diff_bw=flow_diff_bw,
                fb_occ_fw=fb_occ_fw, fb_occ_bw=fb_occ_bw)
     return losses, aux
+
+
+# --------------------------------------------------------------------------- integer census (extension)
+def census_transform(im, max_distance=3, eps=0.9):
+    """[B,H,W,2] uint64 ternary census signature (definition: include/unflow_hip.h)."""
+    im = _f32(im)
+    B, H, W, C = im.shape
+    assert C == 3 and 1 <= max_distance <= 3
+    sig = np.empty((B, H, W, 2), np.uint64)
+    lib().oracle_census_transform(_p(im), sig.ctypes.data_as(ctypes.c_void_p), B, H, W, max_distance,
+                                  ctypes.c_float(eps))
+    return sig
+
+
+def census_hamming(sig1, sig2, mask=None):
+    sig1, sig2 = np.ascontiguousarray(sig1, np.uint64), np.ascontiguousarray(sig2, np.uint64)
+    B, H, W, _ = sig1.shape
+    dist = np.empty((B, H, W), np.int32)
+    m = None if mask is None else _f32(mask)
+    total = lib().oracle_census_hamming(sig1.ctypes.data_as(ctypes.c_void_p), sig2.ctypes.data_as(ctypes.c_void_p),
+                                        _p(m), dist.ctypes.data_as(ctypes.c_void_p), B * H * W)
+    return dist, int(total)
 
 
 # --------------------------------------------------------------------------- stacked-net warp block

@@ -1132,3 +1132,44 @@ void oracle_stacked_inputs(const float *im1, const float *im2, const float *flow
   free(flow);
   free(warp);
 }
+
+/* ---------------------------------------------------------------------------
+ * Integer ternary census + Hamming distance.  NOT a restatement of reference code
+ * (the reference's census is the soft one, D1): the definition of
+ * include/unflow_hip.h, written independently for the CPU.
+ * ------------------------------------------------------------------------- */
+void oracle_census_transform(const float *im, uint64_t *sig, int B, int H, int W, int r, float eps) {
+  const long npix = (long)B * H * W;
+  float *g = (float *)malloc((size_t)npix * sizeof(float));
+  to_gray(im, g, npix);
+#pragma omp parallel for schedule(static)
+  for (long p = 0; p < npix; p++) {
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const long base = p - ((long)y * W + x);
+    uint64_t brighter = 0, darker = 0;
+    int k = 0;
+    for (int i = -r; i <= r; i++)
+      for (int j = -r; j <= r; j++) {
+        if (i == 0 && j == 0) continue;
+        const int yy = y + i, xx = x + j;
+        const float q = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? g[base + (long)yy * W + xx] : 0.0f;
+        const float d = q - g[p];
+        if (d > eps) brighter |= (uint64_t)1 << k;
+        if (d < -eps) darker |= (uint64_t)1 << k;
+        k++;
+      }
+    sig[2 * p] = brighter;
+    sig[2 * p + 1] = darker;
+  }
+  free(g);
+}
+
+uint64_t oracle_census_hamming(const uint64_t *s1, const uint64_t *s2, const float *mask, int32_t *dist, long n) {
+  uint64_t total = 0;
+  for (long p = 0; p < n; p++) {
+    const int d = __builtin_popcountll((s1[2 * p] ^ s2[2 * p]) | (s1[2 * p + 1] ^ s2[2 * p + 1]));
+    if (dist) dist[p] = d;
+    if (!mask || mask[p] != 0.0f) total += (uint64_t)d;
+  }
+  return total;
+}

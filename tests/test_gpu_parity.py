@@ -491,6 +491,26 @@ def test_graph_replay_matches_eager(dev):
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-9)
 
 
+@pytest.mark.parametrize("B,H,W,r,eps", [(2, 37, 53, 3, 0.9), (1, 8, 32, 1, 0.0), (1, 9, 70, 2, 2.5), (1, 1, 1, 3, 0.9)])
+def test_integer_census_bit_exact(oracle_mod, dev, B, H, W, r, eps):
+    """Integer ternary census + popcount Hamming distance (extension): bit-exact, ties included."""
+    from unflow_amd import losses
+    rng = np.random.default_rng(H * 7 + W)
+    im1 = (rng.integers(0, 64, size=(B, H, W, 3)) / 63.0).astype(np.float32)   # quantised: exact ties occur
+    im2 = np.clip(im1 + rng.integers(-2, 3, size=im1.shape) / 63.0, 0, 1).astype(np.float32)
+    mask = (rng.uniform(size=(B, H, W, 1)) > 0.3).astype(np.float32)
+    s1, s2 = losses.census_transform(T(im1, dev), r, eps), losses.census_transform(T(im2, dev), r, eps)
+    w1, w2 = oracle_mod.census_transform(im1, r, eps), oracle_mod.census_transform(im2, r, eps)
+    np.testing.assert_array_equal(N(s1).view(np.uint64), w1)
+    np.testing.assert_array_equal(N(s2).view(np.uint64), w2)
+    dist, total = losses.census_hamming(s1, s2, T(mask, dev))
+    wd, wt = oracle_mod.census_hamming(w1, w2, mask)
+    np.testing.assert_array_equal(N(dist), wd)
+    assert int(total) == wt
+    with pytest.raises(ValueError, match="max_distance"):
+        losses.census_transform(T(im1, dev), 4)
+
+
 def test_empty_inputs(dev):
     from unflow_amd import ops
     from unflow_amd.image_warp import image_warp

@@ -212,6 +212,31 @@ def test_resize_bilinear_and_stacked_inputs(oracle_mod):
     np.testing.assert_array_equal(out, np.concatenate([im1, im2, flow, warp, np.abs(warp - im1)], 3))
 
 
+def test_integer_census_definition(oracle_mod):
+    """Integer ternary census (extension, not in the reference): hand-checked bits."""
+    im = np.zeros((1, 3, 3, 3), np.float32)
+    im[0, 1, 1] = 0.5                      # centre: gray 127.4...
+    im[0, 0, 0] = 1.0                      # neighbour 0 brighter
+    im[0, 1, 2] = 0.5                      # neighbour 4 equal
+    sig = oracle_mod.census_transform(im, 1, eps=0.9)
+    assert sig[0, 1, 1, 0] == 0b00000001                  # only neighbour 0 is brighter
+    assert sig[0, 1, 1, 1] == 0b11101110                  # all others darker except the equal one (bit 4) and bit 0
+    # corner pixel (0,0): its three in-image neighbours (bits 4, 6, 7) and the zero padding (bits 0-3, 5) are all darker
+    assert sig[0, 0, 0, 0] == 0 and sig[0, 0, 0, 1] == 0xFF
+    d, total = oracle_mod.census_hamming(sig, sig)
+    assert total == 0 and not d.any()
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, 4, size=(2, 9, 11, 3)).astype(np.float32) / 3.0     # many exact ties
+    b = rng.integers(0, 4, size=(2, 9, 11, 3)).astype(np.float32) / 3.0
+    sa, sb = oracle_mod.census_transform(a, 3, 0.0), oracle_mod.census_transform(b, 3, 0.0)
+    assert not (sa[..., 0] & sa[..., 1]).any()                              # a neighbour is never both
+    d, total = oracle_mod.census_hamming(sa, sb)
+    x = (sa[..., 0] ^ sb[..., 0]) | (sa[..., 1] ^ sb[..., 1])
+    ref = np.array([bin(int(v)).count("1") for v in x.ravel()]).reshape(x.shape)
+    np.testing.assert_array_equal(d, ref)
+    assert total == ref.sum() and d.max() <= 48
+
+
 def test_seeded_fixture_is_reproducible(seeded, oracle_mod):
     """The committed oracle outputs are what the oracle computes today."""
     c, p0, p1 = oracle_mod.correlation(seeded["corr_f0"], seeded["corr_f1"])

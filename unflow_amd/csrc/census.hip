@@ -421,6 +421,72 @@ __global__ __launch_bounds__(64 * kPairWaves) void ternary_bwd_pair_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Integer ternary census + Hamming distance.  NOT in the
+// reference, whose census is the soft real-valued one above (D1); defined here as
+// the classical ternary transform on the same gray image I = 255*gray(im), same
+// (2r+1)^2 window, same zero padding: neighbour k (row-major, centre skipped) is
+//   brighter  if I[q] - I[p] >  eps      -> bit k of word 0
+//   darker    if I[q] - I[p] < -eps      -> bit k of word 1
+// and the distance of two signatures is the number of neighbours whose ternary
+// digit differs: popcount((b1^b2) | (d1^d2)).  All of it is compares and integer
+// arithmetic on bit-exact gray values (separately rounded products), so the
+// results are bit-exact against the CPU oracle.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kNT) void census_transform_kernel(const float *__restrict__ im,
+                                                               unsigned long long *__restrict__ sig, int H, int W,
+                                                               int r, float eps) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lw = kTW + 2 * r, lh = kTH + 2 * r;
+  const int x0 = blockIdx.x * kTW, y0 = blockIdx.y * kTH;
+  const long long item_px = (long long)blockIdx.z * H * W;
+  for (int i = threadIdx.x; i < lw * lh; i += kNT) {
+    const int ly = i / lw, lx = i - ly * lw;
+    const int y = y0 + ly - r, x = x0 + lx - r;
+    lds[i] = (y >= 0 && y < H && x >= 0 && x < W) ? gray255(im + (item_px + (long long)y * W + x) * 3) : 0.f;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x % kTW, ty = threadIdx.x / kTW;
+  const int x = x0 + tx, y = y0 + ty;
+  if (x >= W || y >= H) return;
+  const float c = lds[(ty + r) * lw + tx + r];
+  unsigned long long brighter = 0, darker = 0;
+  int k = 0;
+  for (int i = 0; i < 2 * r + 1; ++i)
+    for (int j = 0; j < 2 * r + 1; ++j) {
+      if (i == r && j == r) continue;
+      const float d = add_rn(lds[(ty + i) * lw + tx + j], -c);
+      brighter |= (unsigned long long)(d > eps) << k;
+      darker |= (unsigned long long)(d < -eps) << k;
+      ++k;
+    }
+  const long long p = item_px + (long long)y * W + x;
+  sig[2 * p] = brighter;
+  sig[2 * p + 1] = darker;
+}
+
+// per-pixel distance + the masked total; the total is integer, so the wave / block /
+// grid reduction (DPP-free shuffles, then one 64-bit atomic per block) is exact in any order
+__global__ __launch_bounds__(256) void census_hamming_kernel(const ulonglong2 *__restrict__ s1,
+                                                             const ulonglong2 *__restrict__ s2,
+                                                             const float *__restrict__ mask,
+                                                             int *__restrict__ dist,
+                                                             unsigned long long *__restrict__ total, long long n) {
+  unsigned sum = 0;
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    const ulonglong2 a = s1[p], b = s2[p];
+    const int d = __popcll((a.x ^ b.x) | (a.y ^ b.y));
+    if (dist) dist[p] = d;
+    if (!mask || mask[p] != 0.f) sum += (unsigned)d;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, kWave);   // 64-lane reduction
+  __shared__ unsigned red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0 && total) atomicAdd(total, (unsigned long long)red[0] + red[1] + red[2] + red[3]);
+}
+
 // Final pass of every loss reduction: one block, fixed order, double accumulate.
 __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__restrict__ partial, int n,
                                                                double inv_norm, float *__restrict__ loss) {
@@ -686,4 +752,33 @@ extern "C" int unflow_charbonnier_bwd(const float *x, const float *mask, int mas
   hipLaunchKernelGGL(charbonnier_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream), x, mask,
                      mask_channels, gout, dx, n, C, alpha, beta, epsilon, truncate, (float)(1.0 / norm));
   return launch_status("charbonnier_bwd");
+}
+
+extern "C" int unflow_census_transform(const float *im, unsigned long long *signature, int B, int H, int W,
+                                       int max_distance, float eps, unflow_stream_t stream) {
+  if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "census_transform: negative dimension");
+  if (max_distance < 1 || max_distance > 3)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "census_transform: max_distance must be in [1,3] (48 neighbours per 64-bit word)");
+  if (!(eps >= 0.f)) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "census_transform: eps must be >= 0");
+  if ((long long)B * H * W == 0) return UNFLOW_OK;
+  const int r = max_distance;
+  const dim3 grid((W + kTW - 1) / kTW, (H + kTH - 1) / kTH, B);
+  const size_t smem = sizeof(float) * (kTW + 2 * r) * (kTH + 2 * r);
+  hipLaunchKernelGGL(census_transform_kernel, grid, dim3(kNT), smem, as_stream(stream), im, signature, H, W, r, eps);
+  return launch_status("census_transform");
+}
+
+extern "C" int unflow_census_hamming(const unsigned long long *sig1, const unsigned long long *sig2,
+                                     const float *mask, int *dist, unsigned long long *total, int B, int H, int W,
+                                     unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (n < 0 || B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "census_hamming: negative dimension");
+  hipStream_t s = as_stream(stream);
+  if (total && hipMemsetAsync(total, 0, sizeof(unsigned long long), s) != hipSuccess)
+    return launch_status("census_hamming memset");
+  if (n == 0) return UNFLOW_OK;
+  hipLaunchKernelGGL(census_hamming_kernel, dim3(ew_grid(n)), dim3(256), 0, s,
+                     reinterpret_cast<const ulonglong2 *>(sig1), reinterpret_cast<const ulonglong2 *>(sig2), mask, dist,
+                     total, n);
+  return launch_status("census_hamming");
 }

@@ -307,6 +307,41 @@ def ternary_dist(im1, im2_warped, max_distance=1):
     return dist
 
 
+# --------------------------------------------------------------------------- integer census (extension)
+def census_transform(im, max_distance=3, eps=0.9):
+    """Integer ternary census signature [B,H,W,2] (int64 bit patterns) of ``im`` [B,H,W,3].
+    Not part of the reference (whose census is the soft ``ternary_loss``): neighbour k is
+    'brighter' / 'darker' if 255*gray differs from the centre by more than ``eps``."""
+    im = _dev(im, "im")
+    _require_rank4(im, "im")
+    B, H, W, C = im.shape
+    if C != 3:
+        raise ValueError("census_transform expects a [B,H,W,3] image, got %s" % (tuple(im.shape),))
+    sig = torch.empty((B, H, W, 2), device=im.device, dtype=torch.int64)
+    with torch.cuda.device(im.device):
+        _lib.check(_lib.load().unflow_census_transform(_ptr(im), ctypes.c_void_p(sig.data_ptr()), B, H, W,
+                                                       max_distance, eps, _stream()))
+    return sig
+
+
+def census_hamming(sig1, sig2, mask=None):
+    """(dist [B,H,W] int32, total int64 scalar tensor): per-pixel number of differing ternary
+    digits (64-bit popcounts) and its sum over the pixels where ``mask`` is non-zero."""
+    if sig1.shape != sig2.shape or sig1.dtype != torch.int64 or sig2.dtype != torch.int64 or not sig1.is_cuda:
+        raise ValueError("census_hamming expects two int64 [B,H,W,2] signatures on the GPU")
+    B, H, W, _ = sig1.shape
+    sig1, sig2 = sig1.contiguous(), sig2.contiguous()
+    dist = torch.empty((B, H, W), device=sig1.device, dtype=torch.int32)
+    total = torch.empty((), device=sig1.device, dtype=torch.int64)
+    if mask is not None:
+        mask = _dev(mask, "mask")
+    with torch.cuda.device(sig1.device):
+        _lib.check(_lib.load().unflow_census_hamming(
+            ctypes.c_void_p(sig1.data_ptr()), ctypes.c_void_p(sig2.data_ptr()), _ptr(mask),
+            ctypes.c_void_p(dist.data_ptr()), ctypes.c_void_p(total.data_ptr()), B, H, W, _stream()))
+    return dist, total
+
+
 # --------------------------------------------------------------------------- composite
 def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion='',
                    data_max_distance=1, norm_batch=0, terms=None, return_aux=False):
