@@ -217,8 +217,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg3: 384x1280 pairs, batch %d per GPU: 2x FlowNetC correlation fwd+bwd on "
-                                   "[B,256,48,160] + level-0 compute_losses (4 image_warp, fb masks, 2 forward_warp, "
-                                   "2 ternary 7x7) fwd+bwd" % args.batch,
+                                   "[B,256,48,160] + level-0 compute_losses (2 image_warp of the images, fb-occlusion masks with the "
+                                   "2 flow warps computed on the fly, 2 forward_warp + sym term, 2 ternary 7x7) fwd+bwd" % args.batch,
                        "global_batch": args.batch * world, "height": H, "width": W,
                        "parallelism": "batch-sharded x%d, all-reduce of loss + 156.7 MB grad buffer" % world},
             "roofline": {"bound": "mfma",

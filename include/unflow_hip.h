@@ -135,6 +135,17 @@ int unflow_create_mask(float *mask, int B, int H, int W, int pad_top, int pad_bo
  * not NULL it is multiplied by (1 - occ) (losses.py:53-55). */
 int unflow_fb_occlusion(const float *flow, const float *flow_other_warped, float *flow_diff,
                         float *occ, float *mask_inout, int B, int H, int W, unflow_stream_t stream);
+/* The same with flow_other_warped = image_warp(flow_other, flow) (losses.py:38-39) computed on
+ * the fly; flow_other_warped (optional output), occ and mask_inout may be NULL. */
+int unflow_fb_occlusion_warp(const float *flow, const float *flow_other, float *flow_other_warped,
+                             float *occ, float *mask_inout, int B, int H, int W,
+                             unflow_stream_t stream);
+/* One direction of losses['sym'] (losses.py:27-29,57-61): charbonnier_loss((1 - mask) -
+ * cast(density < thresh)), density = forward_warp of the other flow; mask, density
+ * [B,H,W,1].  No gradient (both operands are thresholded maps).  norm_count 0 = B*H*W. */
+int unflow_sym_loss_fwd(const float *mask, const float *density, float thresh, float *loss,
+                        float *workspace, int B, int H, int W, long long norm_count,
+                        unflow_stream_t stream);
 /* charbonnier_loss (losses.py:298-322).  x [B,H,W,C]; mask NULL, [B,H,W,1]
  * (mask_channels 1) or [B,H,W,C].  loss overwritten with sum / norm_count
  * (0 = local B*H*W*C).  truncate <= 0 disables truncation. */

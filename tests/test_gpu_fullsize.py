@@ -134,3 +134,35 @@ def test_census_properties_cfg3(dev):
     # dist_sum bounds: 0 <= D <= P*P
     d = losses.ternary_dist(im1[:4], im2[:4], 3)
     assert float(d.min()) >= 0.0 and float(d.max()) <= 49.0
+
+
+def test_cfg5_shapes_fp32(dev):
+    """BASELINE config 5's shapes (768x1280, batch 16, features [16,256,96,160]) in fp32 --
+    the fp16-storage variant it names is not in the reference and not built.
+    Correlation: adjoint identity and zero-displacement plane; forward_warp: splat mass;
+    stacked-net block: zero flow reproduces [im1, im2, 0, im2, |im2 - im1|]."""
+    from unflow_amd import flownet, ops
+    g = gen(dev, 9)
+    f0 = torch.randn((16, C8, 96, 160), device=dev, generator=g)
+    f1 = torch.randn((16, C8, 96, 160), device=dev, generator=g)
+    c = ops.correlation(f0, f1)
+    assert c.shape == (16, 441, 96, 160)
+    torch.testing.assert_close(c[:, 220], (f0.double() * f1.double()).mean(1).float(), rtol=1e-5, atol=1e-5)
+    top = torch.randn_like(c)
+    g0, g1 = ops.correlation_grad(top, f0, f1)
+    df = torch.randn_like(f0)
+    lhs = (top.double() * ops.correlation(df, f1).double()).sum()
+    rhs = (g0.double() * df.double()).sum()
+    np.testing.assert_allclose(float(lhs), float(rhs), rtol=1e-5)
+    lhs = (top.double() * ops.correlation(f0, df).double()).sum()
+    rhs = (g1.double() * df.double()).sum()
+    np.testing.assert_allclose(float(lhs), float(rhs), rtol=1e-5)
+    del c, top, g0, g1, df, f0, f1
+    flow = torch.zeros((16, 768, 1280, 2), device=dev)
+    out = ops.forward_warp(flow)
+    np.testing.assert_allclose(float(out[:, 10:-10, 10:-10].min()), 6.2831479, rtol=1e-6)
+    np.testing.assert_allclose(float(out[:, 10:-10, 10:-10].max()), 6.2831479, rtol=1e-6)
+    im1 = torch.rand((16, 768, 1280, 3), device=dev, generator=g)
+    im2 = torch.rand((16, 768, 1280, 3), device=dev, generator=g)
+    blk = flownet.stacked_inputs(im1, im2, torch.zeros((16, 192, 320, 2), device=dev))
+    assert torch.equal(blk, torch.cat([im1, im2, torch.zeros_like(flow), im2, (im2 - im1).abs()], 3))

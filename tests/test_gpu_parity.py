@@ -511,6 +511,41 @@ def test_integer_census_bit_exact(oracle_mod, dev, B, H, W, r, eps):
         losses.census_transform(T(im1, dev), 4)
 
 
+def test_fused_loss_glue_matches_composition(oracle_mod, dev):
+    """fb_occlusion_warp == fb_occlusion(image_warp(...)) bitwise; sym_loss == the charbonnier
+    composition; compute_losses without aux (fused path) == with aux (composed path) == oracle."""
+    from unflow_amd import losses
+    from unflow_amd.image_warp import image_warp
+    from unflow_amd.ops import forward_warp
+    rng = np.random.default_rng(55)
+    B, H, W = 2, 40, 56
+    im1, im2, flow_fw = _pair(rng, B, H, W)
+    flow_bw = (-flow_fw + rng.standard_normal(flow_fw.shape) * 0.7).astype(np.float32)
+    ffw, fbw = T(flow_fw, dev), T(flow_bw, dev)
+    border = T(oracle_mod.create_border_mask((B, H, W)), dev)
+    m1, m2 = border.clone(), border.clone()
+    warped, occ1 = losses.fb_occlusion_warp(ffw, fbw, m1, want_warped=True)
+    ref_w = image_warp(fbw, ffw)
+    _, occ2 = losses.fb_occlusion(ffw, ref_w, m2)
+    assert torch.equal(warped, ref_w) and torch.equal(occ1, occ2) and torch.equal(m1, m2)
+    assert 0 < float(occ1.mean()) < 1
+    dens = forward_warp(fbw)
+    got = float(losses.sym_loss(m1, dens))
+    want = float(losses.charbonnier_loss((1 - m1) - (dens < losses.DISOCC_THRESH).float()))
+    np.testing.assert_allclose(got, want, rtol=1e-6)
+    for mo in ("fb", "disocc", ""):
+        fused = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw, border, mo, 2,
+                                      terms=("ternary", "sym", "occ", "smooth_2nd"))
+        full, _ = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw, border, mo, 2, return_aux=True)
+        want, _ = oracle_mod.compute_losses(im1, im2, flow_fw, flow_bw, N(border), mo, 2)
+        assert set(fused) == {"ternary", "sym", "occ", "smooth_2nd"}
+        for k in fused:
+            np.testing.assert_allclose(float(fused[k]), float(full[k]), rtol=1e-6, err_msg=k)
+            np.testing.assert_allclose(float(fused[k]), want[k], rtol=2e-4, err_msg=k)
+    only_smooth = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw, None, "", 1, terms=("smooth_1st",))
+    assert set(only_smooth) == {"smooth_1st"}
+
+
 def test_empty_inputs(dev):
     from unflow_amd import ops
     from unflow_amd.image_warp import image_warp

@@ -14,6 +14,7 @@
 // (2r+1)^2 window out of LDS, so HBM traffic is the 28 B/pixel of the inputs.
 // The kernel is VALU-issue bound: per tap 9 f32 ops + 2 v_rsq_f32 + 1 v_rcp_f32.
 #include "common.h"
+#include "warp_taps.h"
 
 #include <type_traits>
 
@@ -559,23 +560,75 @@ __global__ __launch_bounds__(256) void create_mask_kernel(float *__restrict__ ma
   }
 }
 
+// length_sq test of compute_losses (losses.py:43-51) on one pixel
+__device__ inline float fb_occluded(float2 f, float2 w, float &du, float &dv) {
+  du = f.x + w.x;
+  dv = f.y + w.y;
+  // length_sq = reduce_sum(square(x), 3): separately rounded squares (losses.py:12-13)
+  const float mag_sq = add_rn(add_rn(mul_rn(f.x, f.x), mul_rn(f.y, f.y)), add_rn(mul_rn(w.x, w.x), mul_rn(w.y, w.y)));
+  const float thresh = add_rn(mul_rn(0.01f, mag_sq), 0.5f);
+  const float len = add_rn(mul_rn(du, du), mul_rn(dv, dv));
+  return len > thresh ? 1.f : 0.f;
+}
+
 __global__ __launch_bounds__(256) void fb_occlusion_kernel(const float2 *__restrict__ flow,
                                                            const float2 *__restrict__ other,
                                                            float2 *__restrict__ flow_diff, float *__restrict__ occ,
                                                            float *__restrict__ mask_inout, long long n) {
   for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
-    const float2 f = flow[p], w = other[p];
-    const float du = f.x + w.x, dv = f.y + w.y;
-    // length_sq = reduce_sum(square(x), 3): separately rounded squares (losses.py:12-13)
-    const float mag_sq = add_rn(add_rn(mul_rn(f.x, f.x), mul_rn(f.y, f.y)),
-                                   add_rn(mul_rn(w.x, w.x), mul_rn(w.y, w.y)));
-    const float thresh = add_rn(mul_rn(0.01f, mag_sq), 0.5f);
-    const float len = add_rn(mul_rn(du, du), mul_rn(dv, dv));
-    const float o = len > thresh ? 1.f : 0.f;
+    float du, dv;
+    const float o = fb_occluded(flow[p], other[p], du, dv);
     if (flow_diff) flow_diff[p] = make_float2(du, dv);
     if (occ) occ[p] = o;
     if (mask_inout) mask_inout[p] = mask_inout[p] * (1.f - o);
   }
+}
+
+// The same with flow_other_warped = image_warp(flow_other, flow) computed on the fly
+// (core/image_warp.py order of operations, as image_warp_fwd_kernel<2>): when only the
+// occlusion mask is wanted the warped flow never goes to HBM (52 -> 24 B/pixel).
+__global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__restrict__ flow,
+                                                                const float2 *__restrict__ flow_other,
+                                                                float2 *__restrict__ warped_out,
+                                                                float *__restrict__ occ,
+                                                                float *__restrict__ mask_inout, int H, int W,
+                                                                long long n) {
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    const int x = (int)(p % W);
+    const long long row = p / W;
+    const int y = (int)(row % H);
+    const float2 f = flow[p];
+    const ClampTaps t = clamp_taps(x, y, f, H, W);
+    const float2 *base = flow_other + (row / H) * H * W;
+    const float2 a = base[t.ia], b = base[t.ib], c = base[t.ic], d = base[t.id];
+    const float wa = (1.f - t.xw) * (1.f - t.yw), wb = (1.f - t.xw) * t.yw;
+    const float wc = t.xw * (1.f - t.yw), wd = t.xw * t.yw;
+    float2 w;
+    w.x = add_rn(add_rn(add_rn(mul_rn(wa, a.x), mul_rn(wb, b.x)), mul_rn(wc, c.x)), mul_rn(wd, d.x));
+    w.y = add_rn(add_rn(add_rn(mul_rn(wa, a.y), mul_rn(wb, b.y)), mul_rn(wc, c.y)), mul_rn(wd, d.y));
+    float du, dv;
+    const float o = fb_occluded(f, w, du, dv);
+    if (warped_out) warped_out[p] = w;
+    if (occ) occ[p] = o;
+    if (mask_inout) mask_inout[p] = mask_inout[p] * (1.f - o);
+  }
+}
+
+// losses['sym'] of one direction (losses.py:60-61): charbonnier_loss(occ - disocc) with
+// occ = 1 - mask (:57-58) and disocc = cast(density < thresh) (:27-29), one pass
+// instead of compare, cast, two subtractions and the reduction.
+__global__ __launch_bounds__(256) void sym_loss_kernel(const float *__restrict__ mask,
+                                                       const float *__restrict__ density, float thresh,
+                                                       float *__restrict__ partial, long long n) {
+  float s = 0.f;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float occ = 1.f - mask[i];
+    const float disocc = density[i] < thresh ? 1.f : 0.f;
+    s += charbonnier_term(occ - disocc, 1.f, kAlpha, 1.f, kEps, 0.f);
+  }
+  __shared__ float red[4];
+  s = block_sum<256>(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
 inline unsigned ew_grid(long long n) {
@@ -781,4 +834,33 @@ extern "C" int unflow_census_hamming(const unsigned long long *sig1, const unsig
                      reinterpret_cast<const ulonglong2 *>(sig1), reinterpret_cast<const ulonglong2 *>(sig2), mask, dist,
                      total, n);
   return launch_status("census_hamming");
+}
+
+extern "C" int unflow_fb_occlusion_warp(const float *flow, const float *flow_other, float *flow_other_warped,
+                                        float *occ, float *mask_inout, int B, int H, int W,
+                                        unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp: negative dimension");
+  if (n == 0) return UNFLOW_OK;
+  hipLaunchKernelGGL(fb_occlusion_warp_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other),
+                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_inout, H, W, n);
+  return launch_status("fb_occlusion_warp");
+}
+
+extern "C" int unflow_sym_loss_fwd(const float *mask, const float *density, float thresh, float *loss,
+                                   float *workspace, int B, int H, int W, long long norm_count,
+                                   unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "sym_loss: negative dimension");
+  hipStream_t s = as_stream(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("sym_loss memset");
+    return UNFLOW_OK;
+  }
+  const unsigned grid = ew_grid(n);
+  hipLaunchKernelGGL(sym_loss_kernel, dim3(grid), dim3(256), 0, s, mask, density, thresh, workspace, n);
+  if (int rc = launch_status("sym_loss")) return rc;
+  const double norm = norm_count > 0 ? (double)norm_count : (double)n;
+  return reduce_partials(workspace, (int)grid, 1.0 / norm, loss, s);
 }

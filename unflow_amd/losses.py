@@ -82,6 +82,40 @@ def fb_occlusion(flow, flow_other_warped, mask_inout=None):
     return diff, occ
 
 
+def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False):
+    """``fb_occlusion(flow, image_warp(flow_other, flow), mask_inout)`` in one pass: the warped
+    flow is computed on the fly and only written when ``want_warped``.  Returns (warped or
+    None, occ); no gradient (the occlusion map is a thresholded quantity)."""
+    flow = _dev(flow.detach(), "flow")
+    other = _dev(flow_other.detach(), "flow_other")
+    _check_flow(None, flow)
+    if other.shape != flow.shape:
+        raise ValueError("flow %s and flow_other %s must have the same shape" % (tuple(flow.shape), tuple(other.shape)))
+    B, H, W, _ = flow.shape
+    warped = torch.empty_like(flow) if want_warped else None
+    occ = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
+    with torch.cuda.device(flow.device):
+        _lib.check(_lib.load().unflow_fb_occlusion_warp(_ptr(flow), _ptr(other), _ptr(warped), _ptr(occ),
+                                                        _ptr(mask_inout), B, H, W, _stream()))
+    return warped, occ
+
+
+def sym_loss(mask, density_other, norm_count=0):
+    """One direction of ``losses['sym']`` (losses.py:60-61):
+    ``charbonnier_loss((1 - mask) - cast(density_other < DISOCC_THRESH))`` in one pass."""
+    mask, density_other = _dev(mask.detach(), "mask"), _dev(density_other.detach(), "density_other")
+    _require_rank4(mask, "mask")
+    B, H, W, C = mask.shape
+    if C != 1 or density_other.shape != mask.shape:
+        raise ValueError("sym_loss expects two [B,H,W,1] maps")
+    loss = torch.empty((), device=mask.device, dtype=torch.float32)
+    ws = _workspace(B * H * W, mask.device)
+    with torch.cuda.device(mask.device):
+        _lib.check(_lib.load().unflow_sym_loss_fwd(_ptr(mask), _ptr(density_other), DISOCC_THRESH, _ptr(loss),
+                                                   _ptr(ws), B, H, W, norm_count, _stream()))
+    return loss
+
+
 # --------------------------------------------------------------------------- charbonnier
 class _Charbonnier(torch.autograd.Function):
     @staticmethod
@@ -360,14 +394,22 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     nb = norm_batch or B
     npx = nb * H * W
 
-    im2_warped = image_warp(im2, flow_fw)
-    im1_warped = image_warp(im1, flow_bw)
     want = (lambda k: True) if terms is None else (lambda k: k in terms)
-    disocc_fw = disocc_bw = None
+    im2_warped = im1_warped = None
+    if want('ternary') or want('photo') or want('grad') or return_aux:
+        im2_warped = image_warp(im2, flow_fw)
+        im1_warped = image_warp(im1, flow_bw)
+    # Intermediates are only produced when something asks for them (TF1 runs just the nodes a
+    # fetched tensor needs): the splat densities for 'sym' / 'disocc' / aux, the warped flows
+    # for 'fb' / aux -- otherwise the occlusion test warps the other flow on the fly.
+    dens_fw = dens_bw = disocc_fw = disocc_bw = None
     if want('sym') or mask_occlusion == 'disocc' or return_aux:
+        dens_fw = forward_warp(flow_fw.detach())
+        dens_bw = forward_warp(flow_bw.detach())
+    if mask_occlusion == 'disocc' or return_aux:
         # tf.cast(forward_warp(flow) < DISOCC_THRESH): no gradient through the comparison
-        disocc_fw = (forward_warp(flow_fw.detach()) < DISOCC_THRESH).float()
-        disocc_bw = (forward_warp(flow_bw.detach()) < DISOCC_THRESH).float()
+        disocc_fw = (dens_fw < DISOCC_THRESH).float()
+        disocc_bw = (dens_bw < DISOCC_THRESH).float()
 
     if border_mask is None:
         mask_fw = create_outgoing_mask(flow_fw)
@@ -376,20 +418,24 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
         mask_fw = border_mask.clone()
         mask_bw = border_mask.clone()
 
-    flow_bw_warped = image_warp(flow_bw, flow_fw)
-    flow_fw_warped = image_warp(flow_fw, flow_bw)
-    _, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
-    _, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
+    flow_bw_warped = flow_fw_warped = fb_occ_fw = fb_occ_bw = None
+    if want('fb') or return_aux:
+        flow_bw_warped = image_warp(flow_bw, flow_fw)
+        flow_fw_warped = image_warp(flow_fw, flow_bw)
+        _, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
+        _, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
+    elif mask_occlusion == 'fb':
+        _, fb_occ_fw = fb_occlusion_warp(flow_fw, flow_bw, mask_fw)
+        _, fb_occ_bw = fb_occlusion_warp(flow_bw, flow_fw, mask_bw)
     if mask_occlusion == 'disocc':
         mask_fw = mask_fw * (1 - disocc_bw)
         mask_bw = mask_bw * (1 - disocc_fw)
 
-    occ_fw = 1 - mask_fw
-    occ_bw = 1 - mask_bw
-
     if want('sym'):
-        losses['sym'] = (charbonnier_loss(occ_fw - disocc_bw, norm_count=npx) +
-                         charbonnier_loss(occ_bw - disocc_fw, norm_count=npx))
+        losses['sym'] = sym_loss(mask_fw, dens_bw, norm_count=npx) + sym_loss(mask_bw, dens_fw, norm_count=npx)
+    if want('occ') or return_aux:
+        occ_fw = 1 - mask_fw
+        occ_bw = 1 - mask_bw
     if want('occ'):
         losses['occ'] = (charbonnier_loss(occ_fw, norm_count=npx) +
                          charbonnier_loss(occ_bw, norm_count=npx))
