@@ -269,6 +269,11 @@ def breakdown(wl, fwd_ms, bwd_ms):
     rows.append(("backward_warp_grad C3", timeit(lambda: ops.backward_warp_grad(g3, wl.im2, ffw)), npx * 40))
     rows.append(("forward_warp", timeit(lambda: ops.forward_warp(ffw)), npx * 12))
     rows.append(("forward_warp_grad", timeit(lambda: ops.forward_warp_grad(wl.border, ffw)), npx * 16))
+    # SURVEY 8d "adversarial" set: i.i.d. U(-30,30) flows (worst-case gather / splat locality)
+    adv = (torch.rand((B, H, W, 2), device=ffw.device) - 0.5) * 60.0
+    rows.append(("image_warp C3, i.i.d. +-30 px flows", timeit(lambda: image_warp(wl.im2, adv)), npx * 32))
+    rows.append(("backward_warp C3, i.i.d. +-30 px flows", timeit(lambda: ops.backward_warp(wl.im2, adv)), npx * 32))
+    rows.append(("forward_warp, i.i.d. +-30 px flows", timeit(lambda: ops.forward_warp(adv)), npx * 12))
     x = im2w.clone().requires_grad_(True)
 
     def tern():

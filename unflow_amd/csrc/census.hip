@@ -505,7 +505,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const float *__re
 
 __device__ inline float charbonnier_term(float xr, float m, float alpha, float beta, float eps, float truncate) {
   const float xv = xr * beta;
-  float e = powf(add_rn(mul_rn(xv, xv), eps * eps), alpha) * m;
+  float e = pow_pos(add_rn(mul_rn(xv, xv), eps * eps), alpha) * m;
   if (truncate > 0.f) e = fminf(e, truncate);
   return e;
 }
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(256) void charbonnier_bwd_kernel(const float *__res
     const float xr = x[i];
     const float xv = xr * beta;
     const float base = add_rn(mul_rn(xv, xv), eps * eps);
-    float g = alpha * powf(base, alpha - 1.f) * 2.f * beta * beta * xr * m;
-    if (truncate > 0.f && m * powf(base, alpha) > truncate) g = 0.f;
+    float g = alpha * pow_pos(base, alpha - 1.f) * 2.f * beta * beta * xr * m;
+    if (truncate > 0.f && m * pow_pos(base, alpha) > truncate) g = 0.f;
     dx[i] = go * g;
   }
 }

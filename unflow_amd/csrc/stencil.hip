@@ -46,9 +46,7 @@ __device__ inline bool flow_mask(int k, int H, int W, int y, int x) {
   return k == 0 ? mx : (k == 1 ? my : (mx && my));
 }
 
-// (x^2 + eps^2)^alpha and its derivative, beta = 1.  pow through the hardware
-// log2 / exp2 (1 ulp each): relative error below 1e-6 for bases down to eps^2.
-__device__ inline float pow_pos(float b, float a) { return __builtin_amdgcn_exp2f(a * __builtin_amdgcn_logf(b)); }
+// (x^2 + eps^2)^alpha and its derivative, beta = 1 (pow_pos: common.h)
 __device__ inline float charb(float x) { return pow_pos(add_rn(mul_rn(x, x), kEps * kEps), kAlpha); }
 __device__ inline float dcharb(float x) {
   return kAlpha * pow_pos(add_rn(mul_rn(x, x), kEps * kEps), kAlpha - 1.f) * 2.f * x;
