@@ -118,7 +118,9 @@ int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped, const flo
                             float *loss, float *dldd, float *dist, float *workspace, int B, int H,
                             int W, int max_distance, long long norm_count, unflow_stream_t stream);
 /* Gradient wrt im2_warped (im1 is stop-gradient'd upstream, core/augment.py:53).
- * gout: device scalar upstream gradient (NULL = 1).  dldd from the forward. */
+ * gout: device scalar upstream gradient (NULL = 1).  dldd: the map written by
+ * unflow_ternary_loss_fwd for the same inputs and max_distance (it is zero within
+ * max_distance of every image border, which the kernel relies on). */
 int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped, const float *dldd,
                             const float *gout, float *d_im2_warped, int B, int H, int W,
                             int max_distance, unflow_stream_t stream);
@@ -136,10 +138,12 @@ int unflow_create_mask(float *mask, int B, int H, int W, int pad_top, int pad_bo
 int unflow_fb_occlusion(const float *flow, const float *flow_other_warped, float *flow_diff,
                         float *occ, float *mask_inout, int B, int H, int W, unflow_stream_t stream);
 /* The same with flow_other_warped = image_warp(flow_other, flow) (losses.py:38-39) computed on
- * the fly; flow_other_warped (optional output), occ and mask_inout may be NULL. */
+ * the fly; flow_other_warped (optional output), occ and mask_inout may be NULL.
+ * unwarped_magnitude != 0: the threshold uses |flow_other|^2 at the pixel itself instead of
+ * |flow_other_warped|^2 -- the variant of occlusion() (losses.py:125-134). */
 int unflow_fb_occlusion_warp(const float *flow, const float *flow_other, float *flow_other_warped,
                              float *occ, float *mask_inout, int B, int H, int W,
-                             unflow_stream_t stream);
+                             int unwarped_magnitude, unflow_stream_t stream);
 /* One direction of losses['sym'] (losses.py:27-29,57-61): charbonnier_loss((1 - mask) -
  * cast(density < thresh)), density = forward_warp of the other flow; mask, density
  * [B,H,W,1].  No gradient (both operands are thresholded maps).  norm_count 0 = B*H*W. */

@@ -251,6 +251,19 @@ def ternary_loss_grad(im1, im2_warped, mask, max_distance=1, gout=1.0):
     return d
 
 
+def occlusion(flow_fw, flow_bw):
+    """occlusion() (losses.py:125-134): thresholds from the unwarped magnitudes."""
+    flow_fw, flow_bw = _f32(flow_fw), _f32(flow_bw)
+
+    def lsq(a):
+        return (a[..., 0:1] * a[..., 0:1] + a[..., 1:2] * a[..., 1:2]).astype(np.float32)
+    mag_sq = lsq(flow_fw) + lsq(flow_bw)
+    thresh = np.float32(0.01) * mag_sq + np.float32(0.5)
+    diff_fw = flow_fw + image_warp(flow_bw, flow_fw)
+    diff_bw = flow_bw + image_warp(flow_fw, flow_bw)
+    return (lsq(diff_fw) > thresh).astype(np.float32), (lsq(diff_bw) > thresh).astype(np.float32)
+
+
 # --------------------------------------------------------------------------- 3x3 stencil terms
 def smoothness_deltas(flow, order=1):
     """_smoothness_deltas (order 1, losses.py:206-225) / _second_order_deltas (order 2, :258-287):

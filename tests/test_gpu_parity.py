@@ -542,6 +542,11 @@ def test_fused_loss_glue_matches_composition(oracle_mod, dev):
         for k in fused:
             np.testing.assert_allclose(float(fused[k]), float(full[k]), rtol=1e-6, err_msg=k)
             np.testing.assert_allclose(float(fused[k]), want[k], rtol=2e-4, err_msg=k)
+    # occlusion() (losses.py:125-134): unwarped magnitudes in the threshold
+    got_fw, got_bw = losses.occlusion(ffw, fbw)
+    want_fw, want_bw = oracle_mod.occlusion(flow_fw, flow_bw)
+    assert (N(got_fw) != want_fw).mean() < 1e-3 and (N(got_bw) != want_bw).mean() < 1e-3
+    assert 0 < want_fw.mean() < 1
     only_smooth = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw, None, "", 1, terms=("smooth_1st",))
     assert set(only_smooth) == {"smooth_1st"}
 

@@ -364,21 +364,24 @@ __global__ __launch_bounds__(64 * kPairWaves) void ternary_bwd_pair_kernel(
     const float *__restrict__ gout, float *__restrict__ d_im2, int H, int W) {
   using HP = HalfPlane<R, ROWS>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *g1 = lds, *g2 = lds + HP::LW * HP::LH, *gd = lds + 2 * HP::LW * HP::LH;
+  float *g1 = lds, *g2 = lds + HP::LW * HP::LH;
   const int x0 = blockIdx.x * HP::COLS, y0 = blockIdx.y * (kPairWaves * ROWS);
   const long long item_px = (long long)blockIdx.z * H * W;
   stage_gray_pair<R, ROWS>(im1, im2, g1, g2, item_px, H, W, x0, y0);
-  for (int i = threadIdx.x; i < HP::LW * HP::LH; i += 64 * kPairWaves) {
-    const int ly = i / HP::LW, lx = i - ly * HP::LW;
-    const int y = y0 + ly - R, x = x0 + lx - 2 * R;
-    gd[i] = (y >= 0 && y < H && x >= 0 && x < W) ? dldd[item_px + (long long)y * W + x] : 0.f;
-  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = x0 - R + lane;
   const bool col_ok = lane >= R && lane < 64 - R && x < W;
   const float go = (gout ? *gout : 1.f) * (0.2f * 0.81f);
+  // dldd is read straight from HBM/L2 with LINEAR addressing: it is zero within R of
+  // every image border (create_mask of the forward), so a tap that leaves the image
+  // lands, through the row / item wrap-around, on a zero, and reads outside the
+  // buffer return 0 through the descriptor's range check.  Only the centre value of
+  // a lane that is itself outside the image has to be forced to zero.
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(dldd), (short)0, (int)((long long)gridDim.z * H * W * 4), 0x00020000);
+  const int rowb = W * 4;
   float ring[R + 1];
 #pragma unroll
   for (int i = 0; i <= R; ++i) ring[i] = 0.f;
@@ -387,14 +390,19 @@ __global__ __launch_bounds__(64 * kPairWaves) void ternary_bwd_pair_kernel(
     const int ly = wave * ROWS + it;
     const int y = y0 - R + ly;
     const int c = ly * HP::LW + lane + R;
-    const float *p1 = g1 + c, *p2 = g2 + c, *pd = gd + c;
-    const float c1 = p1[0], c2 = p2[0], cd = pd[0];
+    const float *p1 = g1 + c, *p2 = g2 + c;
+    const int pb = (int)((item_px + (long long)y * W + x) * 4);     // byte offset of (y, x); may be negative
+    auto gdl = [&](int dy, int dx) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, pb + dx * 4, dy * rowb, 0));
+    };
+    const bool inside = x >= 0 && x < W && y >= 0 && y < H;
+    const float c1 = p1[0], c2 = p2[0], cd = inside ? gdl(0, 0) : 0.f;
     const v2f c1v = {c1, c1}, c2v = {c2, c2}, cdv = {cd, cd};
     v2f own = {0.f, 0.f};
     static_for_pairs<0, HP::N>([&](auto K) {
       constexpr int ka = decltype(K)::value, kb = ka + 1;
       constexpr int oa = HP::dy(ka) * HP::LW + HP::dx(ka), ob = HP::dy(kb) * HP::LW + HP::dx(kb);
-      const v2f w = cdv + v2f{pd[oa], pd[ob]};
+      const v2f w = cdv + v2f{gdl(HP::dy(ka), HP::dx(ka)), gdl(HP::dy(kb), HP::dx(kb))};
       const v2f d1 = v2f{p1[oa], p1[ob]} - c1v, d2 = v2f{p2[oa], p2[ob]} - c2v;
       const v2f s1 = pk_fma(d1, d1, v2f{0.81f, 0.81f}), s2 = pk_fma(d2, d2, v2f{0.81f, 0.81f});
       const v2f r1 = {__builtin_amdgcn_rsqf(s1.x), __builtin_amdgcn_rsqf(s1.y)};
@@ -560,12 +568,13 @@ __global__ __launch_bounds__(256) void create_mask_kernel(float *__restrict__ ma
   }
 }
 
-// length_sq test of compute_losses (losses.py:43-51) on one pixel
-__device__ inline float fb_occluded(float2 f, float2 w, float &du, float &dv) {
+// length_sq test of compute_losses (losses.py:43-51) on one pixel; m = the flow whose
+// magnitude enters the threshold (the warped one there, the unwarped one in occlusion(), :126)
+__device__ inline float fb_occluded(float2 f, float2 w, float2 m, float &du, float &dv) {
   du = f.x + w.x;
   dv = f.y + w.y;
   // length_sq = reduce_sum(square(x), 3): separately rounded squares (losses.py:12-13)
-  const float mag_sq = add_rn(add_rn(mul_rn(f.x, f.x), mul_rn(f.y, f.y)), add_rn(mul_rn(w.x, w.x), mul_rn(w.y, w.y)));
+  const float mag_sq = add_rn(add_rn(mul_rn(f.x, f.x), mul_rn(f.y, f.y)), add_rn(mul_rn(m.x, m.x), mul_rn(m.y, m.y)));
   const float thresh = add_rn(mul_rn(0.01f, mag_sq), 0.5f);
   const float len = add_rn(mul_rn(du, du), mul_rn(dv, dv));
   return len > thresh ? 1.f : 0.f;
@@ -577,7 +586,7 @@ __global__ __launch_bounds__(256) void fb_occlusion_kernel(const float2 *__restr
                                                            float *__restrict__ mask_inout, long long n) {
   for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
     float du, dv;
-    const float o = fb_occluded(flow[p], other[p], du, dv);
+    const float o = fb_occluded(flow[p], other[p], other[p], du, dv);
     if (flow_diff) flow_diff[p] = make_float2(du, dv);
     if (occ) occ[p] = o;
     if (mask_inout) mask_inout[p] = mask_inout[p] * (1.f - o);
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__
                                                                 float2 *__restrict__ warped_out,
                                                                 float *__restrict__ occ,
                                                                 float *__restrict__ mask_inout, int H, int W,
-                                                                long long n) {
+                                                                int unwarped_magnitude, long long n) {
   for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
     const int x = (int)(p % W);
     const long long row = p / W;
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__
     w.x = add_rn(add_rn(add_rn(mul_rn(wa, a.x), mul_rn(wb, b.x)), mul_rn(wc, c.x)), mul_rn(wd, d.x));
     w.y = add_rn(add_rn(add_rn(mul_rn(wa, a.y), mul_rn(wb, b.y)), mul_rn(wc, c.y)), mul_rn(wd, d.y));
     float du, dv;
-    const float o = fb_occluded(f, w, du, dv);
+    const float o = fb_occluded(f, w, unwarped_magnitude ? flow_other[p] : w, du, dv);
     if (warped_out) warped_out[p] = w;
     if (occ) occ[p] = o;
     if (mask_inout) mask_inout[p] = mask_inout[p] * (1.f - o);
@@ -636,10 +645,11 @@ inline unsigned ew_grid(long long n) {
   return (unsigned)(g < kReduceBlocks ? (g > 0 ? g : 1) : kReduceBlocks);
 }
 
-// Rows per wave strip.  Forward: two LDS images, 39 KB per workgroup.  Backward: three
-// images; with 16 rows (59 KB) only two workgroups fit a CU and the kernel is SLOWER
-// than the unpaired one (0.47 vs 0.42 ms); with 8 rows (32 KB) it is 0.38 ms.
-constexpr int kPairRowsFwd = 16, kPairRowsBwd = 8;
+// Rows per wave strip: two gray LDS images of 70 x 70 floats, 39 KB per workgroup.  (A
+// backward with dldd as a third LDS image fits only two workgroups per CU at 16 rows and
+// is slower than the unpaired kernel, 0.47 vs 0.42 ms; 0.38 ms at 8 rows; 0.31 ms with
+// dldd read in place.)
+constexpr int kPairRowsFwd = 16;
 inline dim3 pair_grid(int r, int rows_per_wave, int B, int H, int W) {
   const int cols = 64 - 2 * r, rows = kPairWaves * rows_per_wave;
   return dim3((W + cols - 1) / cols, (H + rows - 1) / rows, B);
@@ -720,10 +730,10 @@ extern "C" int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped
   if ((long long)B * H * W == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
   const int r = max_distance;
-  if (r >= 2 && r <= 3) {
+  if (r >= 2 && r <= 3 && (long long)B * H * W * 4 < (1LL << 31)) {   // 32-bit byte offsets into dldd
 #define LAUNCH_PAIR_BWD(R)                                                                                     \
-  hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, kPairRowsBwd>), pair_grid(r, kPairRowsBwd, B, H, W),           \
-                     dim3(64 * kPairWaves), (pair_smem<R, kPairRowsBwd>(3)), s, im1, im2_warped, dldd, gout,    \
+  hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, kPairRowsFwd>), pair_grid(r, kPairRowsFwd, B, H, W),           \
+                     dim3(64 * kPairWaves), (pair_smem<R, kPairRowsFwd>(2)), s, im1, im2_warped, dldd, gout,    \
                      d_im2_warped, H, W)
     if (r == 2) LAUNCH_PAIR_BWD(2);
     else LAUNCH_PAIR_BWD(3);
@@ -838,13 +848,13 @@ extern "C" int unflow_census_hamming(const unsigned long long *sig1, const unsig
 
 extern "C" int unflow_fb_occlusion_warp(const float *flow, const float *flow_other, float *flow_other_warped,
                                         float *occ, float *mask_inout, int B, int H, int W,
-                                        unflow_stream_t stream) {
+                                        int unwarped_magnitude, unflow_stream_t stream) {
   const long long n = (long long)B * H * W;
   if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp: negative dimension");
   if (n == 0) return UNFLOW_OK;
   hipLaunchKernelGGL(fb_occlusion_warp_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other),
-                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_inout, H, W, n);
+                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_inout, H, W, unwarped_magnitude, n);
   return launch_status("fb_occlusion_warp");
 }
 

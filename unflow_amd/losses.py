@@ -5,9 +5,9 @@ Same function names and signatures as the reference: ``ternary_loss``
 ``create_border_mask`` (:338), ``create_outgoing_mask`` (:347), ``length_sq``
 (:12), ``photometric_loss`` (:198), ``gradient_loss`` (:244), ``smoothness_loss``
 (:250), ``second_order_loss`` (:290), their ``_*_deltas`` helpers, and
-``compute_losses`` (:16-87) with all eight entries of its dict.  ``occlusion``
-(:125), ``divergence`` (:147) and ``diffusion_loss`` (:173) have no caller on
-the training path and are not mirrored.
+``compute_losses`` (:16-87) with all eight entries of its dict, and ``occlusion``
+(:125).  ``divergence`` (:147), ``norm`` (:165) and ``diffusion_loss`` (:173) have
+no caller anywhere in the reference and are not mirrored.
 """
 import ctypes
 import math
@@ -82,7 +82,7 @@ def fb_occlusion(flow, flow_other_warped, mask_inout=None):
     return diff, occ
 
 
-def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False):
+def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False, unwarped_magnitude=False):
     """``fb_occlusion(flow, image_warp(flow_other, flow), mask_inout)`` in one pass: the warped
     flow is computed on the fly and only written when ``want_warped``.  Returns (warped or
     None, occ); no gradient (the occlusion map is a thresholded quantity)."""
@@ -96,8 +96,17 @@ def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False):
     occ = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
     with torch.cuda.device(flow.device):
         _lib.check(_lib.load().unflow_fb_occlusion_warp(_ptr(flow), _ptr(other), _ptr(warped), _ptr(occ),
-                                                        _ptr(mask_inout), B, H, W, _stream()))
+                                                        _ptr(mask_inout), B, H, W,
+                                                        int(bool(unwarped_magnitude)), _stream()))
     return warped, occ
+
+
+def occlusion(flow_fw, flow_bw):
+    """(occ_fw, occ_bw) of ``occlusion`` (losses.py:125-134), the evaluation-time variant
+    (core/train.py:350) whose threshold uses the magnitudes of the UNWARPED flows."""
+    _, occ_fw = fb_occlusion_warp(flow_fw, flow_bw, unwarped_magnitude=True)
+    _, occ_bw = fb_occlusion_warp(flow_bw, flow_fw, unwarped_magnitude=True)
+    return occ_fw, occ_bw
 
 
 def sym_loss(mask, density_other, norm_count=0):
