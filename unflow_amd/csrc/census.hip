@@ -604,13 +604,14 @@ __global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__
                                                                 float *__restrict__ occ,
                                                                 float *__restrict__ mask_inout, int H, int W,
                                                                 int unwarped_magnitude, long long n) {
-  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
-    const int x = (int)(p % W);
-    const long long row = p / W;
-    const int y = (int)(row % H);
+  for (long long v = blockIdx.x * 256LL + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
+    const TiledPixel tp = tiled_pixel(v, H, W);   // n = tiled_total(B, H, W): 64x4 pixel tiles
+    if (!tp.ok) continue;
+    const long long p = tp.idx;
+    const int x = tp.x, y = tp.y;
     const float2 f = flow[p];
     const ClampTaps t = clamp_taps(x, y, f, H, W);
-    const float2 *base = flow_other + (row / H) * H * W;
+    const float2 *base = flow_other + tp.b * H * W;
     const float2 a = base[t.ia], b = base[t.ib], c = base[t.ic], d = base[t.id];
     const float wa = (1.f - t.xw) * (1.f - t.yw), wb = (1.f - t.xw) * t.yw;
     const float wc = t.xw * (1.f - t.yw), wd = t.xw * t.yw;
@@ -854,9 +855,10 @@ extern "C" int unflow_fb_occlusion_warp(const float *flow, const float *flow_oth
   const long long n = (long long)B * H * W;
   if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp: negative dimension");
   if (n == 0) return UNFLOW_OK;
-  hipLaunchKernelGGL(fb_occlusion_warp_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream),
+  const long long vn = tiled_total(B, H, W);
+  hipLaunchKernelGGL(fb_occlusion_warp_kernel, dim3(ew_grid(vn)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other),
-                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_inout, H, W, unwarped_magnitude, n);
+                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_inout, H, W, unwarped_magnitude, vn);
   return launch_status("fb_occlusion_warp");
 }
 

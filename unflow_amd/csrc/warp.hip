@@ -50,12 +50,12 @@ __global__ __launch_bounds__(kBlock) void backward_warp_fwd_kernel(const float *
                                                                    float *__restrict__ output, int H, int W,
                                                                    int channels, long long total) {
   const int nc = C > 0 ? C : channels;
-  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * kBlock) {
-    const int src_x = (int)(idx % W);
-    const long long row = idx / W;
-    const int src_y = (int)(row % H);
-    const long long b = row / H;
+  for (long long v = blockIdx.x * (long long)kBlock + threadIdx.x; v < total;
+       v += (long long)gridDim.x * kBlock) {
+    const TiledPixel tp = tiled_pixel(v, H, W);   // total = tiled_total(B, H, W)
+    if (!tp.ok) continue;
+    const long long idx = tp.idx, b = tp.b;
+    const int src_x = tp.x, src_y = tp.y;
     const Taps t = position_taps(src_x, src_y, flows[idx]);
     const bool in_x0 = t.x0 >= 0 && t.x0 < W, in_x1 = t.x1 >= 0 && t.x1 < W;
     const bool in_y0 = t.y0 >= 0 && t.y0 < H, in_y1 = t.y1 >= 0 && t.y1 < H;
@@ -109,12 +109,12 @@ __global__ __launch_bounds__(kBlock) void backward_warp_bwd_kernel(const float *
                                                                    float2 *__restrict__ output_grad, int H,
                                                                    int W, int channels, long long total) {
   const int nc = C > 0 ? C : channels;
-  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * kBlock) {
-    const int src_x = (int)(idx % W);
-    const long long row = idx / W;
-    const int src_y = (int)(row % H);
-    const long long b = row / H;
+  for (long long v = blockIdx.x * (long long)kBlock + threadIdx.x; v < total;
+       v += (long long)gridDim.x * kBlock) {
+    const TiledPixel tp = tiled_pixel(v, H, W);   // total = tiled_total(B, H, W)
+    if (!tp.ok) continue;
+    const long long idx = tp.idx, b = tp.b;
+    const int src_x = tp.x, src_y = tp.y;
     const Taps t = position_taps(src_x, src_y, flows[idx]);
     const bool in_x0 = t.x0 >= 0 && t.x0 < W, in_x1 = t.x1 >= 0 && t.x1 < W;
     const bool in_y0 = t.y0 >= 0 && t.y0 < H, in_y1 = t.y1 >= 0 && t.y1 < H;
@@ -168,12 +168,12 @@ __global__ __launch_bounds__(kBlock) void image_warp_fwd_kernel(const float *__r
                                                                 float *__restrict__ warped, int H, int W,
                                                                 int channels, long long total) {
   const int nc = C > 0 ? C : channels;
-  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * kBlock) {
-    const int pos_x = (int)(idx % W);
-    const long long row = idx / W;
-    const int pos_y = (int)(row % H);
-    const long long b = row / H;
+  for (long long v = blockIdx.x * (long long)kBlock + threadIdx.x; v < total;
+       v += (long long)gridDim.x * kBlock) {
+    const TiledPixel tp = tiled_pixel(v, H, W);   // total = tiled_total(B, H, W)
+    if (!tp.ok) continue;
+    const long long idx = tp.idx, b = tp.b;
+    const int pos_x = tp.x, pos_y = tp.y;
     const ClampTaps t = clamp_taps(pos_x, pos_y, flow[idx], H, W);
     const float *base = im + b * H * W * nc;
     const float *pa = base + t.ia * nc, *pb = base + t.ib * nc;
@@ -215,12 +215,12 @@ __global__ __launch_bounds__(kBlock) void image_warp_bwd_kernel(const float *__r
                                                                 int channels, long long total) {
   const int nc = C > 0 ? C : channels;
   constexpr int NC = C > 0 ? C : 1;
-  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * kBlock) {
-    const int pos_x = (int)(idx % W);
-    const long long row = idx / W;
-    const int pos_y = (int)(row % H);
-    const long long b = row / H;
+  for (long long v = blockIdx.x * (long long)kBlock + threadIdx.x; v < total;
+       v += (long long)gridDim.x * kBlock) {
+    const TiledPixel tp = tiled_pixel(v, H, W);   // total = tiled_total(B, H, W)
+    if (!tp.ok) continue;
+    const long long idx = tp.idx, b = tp.b;
+    const int pos_x = tp.x, pos_y = tp.y;
     const ClampTaps t = clamp_taps(pos_x, pos_y, flow[idx], H, W);
     const long long item = b * H * W * nc;
     const float wa = (1.f - t.xw) * (1.f - t.yw);
@@ -427,12 +427,12 @@ __global__ __launch_bounds__(kBlock) void forward_warp_bwd_kernel(const float *_
                                                                   float2 *__restrict__ output_grad, int H,
                                                                   int W, long long total) {
   // du = sum_n 2*din[n]*w(n)*(n_x - t_x)/2,  w separable: 9 + 9 exponentials per pixel
-  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * kBlock) {
-    const int src_x = (int)(idx % W);
-    const long long row = idx / W;
-    const int src_y = (int)(row % H);
-    const long long b = row / H;
+  for (long long v = blockIdx.x * (long long)kBlock + threadIdx.x; v < total;
+       v += (long long)gridDim.x * kBlock) {
+    const TiledPixel tp = tiled_pixel(v, H, W);   // total = tiled_total(B, H, W)
+    if (!tp.ok) continue;
+    const long long idx = tp.idx, b = tp.b;
+    const int src_x = tp.x, src_y = tp.y;
     const Window w = splat_window(src_x, src_y, flows[idx], H, W);
     float du = 0.f, dv = 0.f;
     if (w.any) {
@@ -522,10 +522,11 @@ extern "C" int unflow_backward_warp_fwd(const float *images, const float *flows,
                                         int W, int C, unflow_stream_t stream) {
   if (int rc = check_dims("backward_warp", B, H, W, C)) return rc;
   const long long total = (long long)B * H * W;
+  const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0 || C == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
-  const unsigned grid = grid_for(total);
-  DISPATCH_C(backward_warp_fwd_kernel, C, images, reinterpret_cast<const float2 *>(flows), output, H, W, C, total);
+  const unsigned grid = grid_for(vtotal);
+  DISPATCH_C(backward_warp_fwd_kernel, C, images, reinterpret_cast<const float2 *>(flows), output, H, W, C, vtotal);
   return launch_status("backward_warp_fwd");
 }
 
@@ -534,11 +535,12 @@ extern "C" int unflow_backward_warp_bwd(const float *input_grad, const float *im
                                         unflow_stream_t stream) {
   if (int rc = check_dims("backward_warp_grad", B, H, W, C)) return rc;
   const long long total = (long long)B * H * W;
+  const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
-  const unsigned grid = grid_for(total);
+  const unsigned grid = grid_for(vtotal);
   DISPATCH_C(backward_warp_bwd_kernel, C, input_grad, images, reinterpret_cast<const float2 *>(flows),
-             reinterpret_cast<float2 *>(output_grad), H, W, C, total);
+             reinterpret_cast<float2 *>(output_grad), H, W, C, vtotal);
   return launch_status("backward_warp_bwd");
 }
 
@@ -546,10 +548,11 @@ extern "C" int unflow_image_warp_fwd(const float *im, const float *flow, float *
                                      int C, unflow_stream_t stream) {
   if (int rc = check_dims("image_warp", B, H, W, C)) return rc;
   const long long total = (long long)B * H * W;
+  const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0 || C == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
-  const unsigned grid = grid_for(total);
-  DISPATCH_C(image_warp_fwd_kernel, C, im, reinterpret_cast<const float2 *>(flow), warped, H, W, C, total);
+  const unsigned grid = grid_for(vtotal);
+  DISPATCH_C(image_warp_fwd_kernel, C, im, reinterpret_cast<const float2 *>(flow), warped, H, W, C, vtotal);
   return launch_status("image_warp_fwd");
 }
 
@@ -557,16 +560,17 @@ extern "C" int unflow_image_warp_bwd(const float *grad, const float *im, const f
                                      float *d_flow, int B, int H, int W, int C, unflow_stream_t stream) {
   if (int rc = check_dims("image_warp_grad", B, H, W, C)) return rc;
   const long long total = (long long)B * H * W;
+  const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0 || (!d_im && !d_flow)) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
   if (d_im && C > 0) {
     if (hipMemsetAsync(d_im, 0, sizeof(float) * (size_t)total * C, s) != hipSuccess)
       return launch_status("image_warp_bwd memset");
   }
-  const unsigned grid = grid_for(total);
+  const unsigned grid = grid_for(vtotal);
 #define IW_BWD(C_, IM_, FL_)                                                                              \
   hipLaunchKernelGGL((image_warp_bwd_kernel<C_, IM_, FL_>), dim3(grid), dim3(kBlock), 0, s, grad, im,     \
-                     reinterpret_cast<const float2 *>(flow), d_im, reinterpret_cast<float2 *>(d_flow), H, W, C, total)
+                     reinterpret_cast<const float2 *>(flow), d_im, reinterpret_cast<float2 *>(d_flow), H, W, C, vtotal)
 #define IW_BWD_C(IM_, FL_)                   \
   switch (C) {                               \
     case 1: IW_BWD(1, IM_, FL_); break;      \
@@ -599,11 +603,12 @@ extern "C" int unflow_forward_warp_bwd(const float *input_grad, const float *flo
                                        int H, int W, unflow_stream_t stream) {
   if (int rc = check_dims("forward_warp_grad", B, H, W, 2)) return rc;
   const long long total = (long long)B * H * W;
+  const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(forward_warp_bwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, input_grad,
+  hipLaunchKernelGGL(forward_warp_bwd_kernel, dim3(grid_for(vtotal)), dim3(kBlock), 0, s, input_grad,
                      reinterpret_cast<const float2 *>(flows), reinterpret_cast<float2 *>(output_grad), H, W,
-                     total);
+                     vtotal);
   return launch_status("forward_warp_bwd");
 }
 
