@@ -16,6 +16,8 @@
 #include "common.h"
 #include "warp_taps.h"
 
+#include <cstdint>
+
 namespace unflow {
 namespace {
 
@@ -87,8 +89,8 @@ __global__ __launch_bounds__(kBlock) void resize_bilinear_bwd_kernel(const float
   }
 }
 
-// One block = 256 consecutive pixels (flat index over B*H*W); their 14 output
-// floats are assembled in LDS and stored as float4 pieces of one contiguous span.
+// One block = one 64x4 pixel tile; the 14 output floats of its pixels are assembled
+// in LDS and stored as float4 pieces of four contiguous 3.5 KB row spans.
 __global__ __launch_bounds__(kBlock) void stacked_inputs_kernel(const float *__restrict__ im1,
                                                                 const float *__restrict__ im2,
                                                                 const float2 *__restrict__ flow_lr,
@@ -96,13 +98,11 @@ __global__ __launch_bounds__(kBlock) void stacked_inputs_kernel(const float *__r
                                                                 int W, float sh, float sw, float mult,
                                                                 long long total) {
   __shared__ __attribute__((aligned(16))) float tile[kBlock * 14];
-  const long long p0 = blockIdx.x * (long long)kBlock;
-  const long long idx = p0 + threadIdx.x;
-  if (idx < total) {
-    const int x = (int)(idx % W);
-    const long long row = idx / W;
-    const int y = (int)(row % H);
-    const long long b = row / H;
+  // one block = one 64x4 pixel tile (see tiled_pixel): 5 rows of im2 for 4 rows of taps
+  const TiledPixel tp = tiled_pixel(blockIdx.x * (long long)kBlock + threadIdx.x, H, W);
+  if (tp.ok) {
+    const long long idx = tp.idx, b = tp.b;
+    const int x = tp.x, y = tp.y;
     const ResizeTaps r = resize_taps(y, x, h, w, sh, sw);
     const float2 *fb = flow_lr + b * h * w;
     const float2 tl = fb[(long long)r.y0 * w + r.x0], tr = fb[(long long)r.y0 * w + r.x1];
@@ -138,13 +138,20 @@ __global__ __launch_bounds__(kBlock) void stacked_inputs_kernel(const float *__r
     o[7] = f.y;
   }
   __syncthreads();
-  const long long nvalid = min((long long)kBlock, total - p0) * 14;   // floats of this block
-  float *dst = out + p0 * 14;                                         // 14336-byte aligned block spans
-  for (int i = threadIdx.x * 4; i < nvalid; i += kBlock * 4) {
-    if (i + 3 < nvalid) {
-      *reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(tile + i);
-    } else {
-      for (int j = i; j < nvalid; ++j) dst[j] = tile[j];
+  // each tile row is one contiguous span of (valid pixels) * 14 floats in the output
+  const TiledPixel t0 = tiled_pixel(blockIdx.x * (long long)kBlock, H, W);   // first pixel of the tile
+  const int nvx = min(kTileW, W - t0.x) * 14;                                 // floats per tile row
+  for (int rrow = 0; rrow < kTileH; ++rrow) {
+    if (t0.y + rrow >= H) break;
+    float *dst = out + ((t0.b * H + t0.y + rrow) * W + t0.x) * 14;            // 3584-byte aligned when W % 64 == 0
+    const float *src = tile + rrow * kTileW * 14;
+    const bool vec = (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int i = threadIdx.x * 4; i < nvx; i += kBlock * 4) {
+      if (vec && i + 3 < nvx) {
+        *reinterpret_cast<float4 *>(dst + i) = *reinterpret_cast<const float4 *>(src + i);
+      } else {
+        for (int j = i; j < min(i + 4, nvx); ++j) dst[j] = src[j];
+      }
     }
   }
 }
@@ -203,7 +210,7 @@ extern "C" int unflow_stacked_inputs_fwd(const float *im1, const float *im2, con
   if (int rc = check_resize("stacked_inputs", B, h, w, H, W, 2)) return rc;
   const long long total = (long long)B * H * W;
   if (total == 0) return UNFLOW_OK;
-  const long long blocks = (total + kBlock - 1) / kBlock;
+  const long long blocks = tiled_total(B, H, W) / kBlock;
   if (blocks > 0x7fffffffLL) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "stacked_inputs: too many pixels for one launch");
   const float sh = (float)h / (float)H, sw = (float)w / (float)W;
   hipLaunchKernelGGL(stacked_inputs_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, as_stream(stream), im1, im2,
