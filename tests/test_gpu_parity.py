@@ -298,6 +298,23 @@ def test_census_vs_oracle(oracle_mod, dev, B, H, W, r):
     close(x.grad, want_grad, 1e-4, 1e-4 * np.abs(want_grad).max())
 
 
+def test_census_backward_ignores_memory_past_its_buffers(oracle_mod, dev):
+    """The pair-symmetric backward reads dldd with linear addressing and relies on the buffer
+    descriptor's range check past the end: poison the allocator's free memory first."""
+    from unflow_amd import losses
+    rng = np.random.default_rng(91)
+    B, H, W = 2, 40, 70
+    im1, im2, _ = _pair(rng, B, H, W)
+    mask = np.ones((B, H, W, 1), np.float32)
+    want = oracle_mod.ternary_loss_grad(im1, im2, mask, 3)
+    for _ in range(3):
+        poison = torch.full((64 * 1024 * 1024 // 4,), 1e30, device=dev)   # 64 MB of 1e30 ...
+        del poison                                                       # ... back to the caching allocator
+        x = T(im2, dev).requires_grad_(True)
+        losses.ternary_loss(T(im1, dev), x, T(mask, dev), max_distance=3).backward()
+        close(x.grad, want, 1e-4, 1e-4 * np.abs(want).max())
+
+
 def test_charbonnier_and_masks_vs_oracle(oracle_mod, dev):
     from unflow_amd import losses
     rng = np.random.default_rng(5)

@@ -394,8 +394,10 @@ __global__ __launch_bounds__(64 * kPairWaves) void ternary_bwd_pair_kernel(
     const int c = ly * HP::LW + lane + R;
     const float *p1 = g1 + c, *p2 = g2 + c;
     const int pb = (int)((item_px + (long long)y * W + x) * 4);     // byte offset of (y, x); may be negative
+    // the whole offset goes into the VGPR operand: the descriptor's range check covers the
+    // vector and immediate offsets only, not an SGPR offset
     auto gdl = [&](int dy, int dx) {
-      return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, pb + dx * 4, dy * rowb, 0));
+      return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rd, pb + dy * rowb + dx * 4, 0, 0));
     };
     const bool inside = x >= 0 && x < W && y >= 0 && y < H;
     const float c1 = p1[0], c2 = p2[0], cd = inside ? gdl(0, 0) : 0.f;
