@@ -116,8 +116,9 @@ def test_forward_warp_mass_cfg3(dev):
     interior = out[:, 20:H - 20, 20:W - 20, 0]
     np.testing.assert_allclose(float(interior.min()), s, rtol=2e-6)
     np.testing.assert_allclose(float(interior.max()), s, rtol=2e-6)
-    # deterministic inside a window: two launches agree bitwise on a coherent flow
-    assert torch.equal(ops.forward_warp(flow), out)
+    # the in-window sums are integer (order independent); only cells fed by several tiles see
+    # float atomics in varying order: two launches agree to the last bits
+    torch.testing.assert_close(ops.forward_warp(flow), out, rtol=1e-6, atol=1e-6)
 
 
 def test_census_properties_cfg3(dev):
