@@ -303,6 +303,13 @@ def breakdown(wl, fwd_ms, bwd_ms):
         loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, kitti)
         loss.backward()
     rows.append(("pyramid loss, 5 levels H/4..H/64, kitti weights, fwd+bwd", timeit(pyr), 0))
+    from unflow_amd import graph as ugraph
+
+    def pyr_step():
+        loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, kitti)
+        return (loss,) + torch.autograd.grad(loss, pf + pb)
+    gs = ugraph.GraphedStep(pyr_step)
+    rows.append(("  the same as one HIP graph (unflow_amd.graph.GraphedStep)", timeit(gs.replay), 0))
     from unflow_amd import flownet
     flr = torch.randn((B, H // 4, W // 4, 2), device=ffw.device, generator=g) * 0.3
     rows.append(("stacked_inputs (resize+warp+abs+concat, 14 ch)", timeit(lambda: flownet.stacked_inputs(wl.im1, wl.im2, flr)), npx * 80))
