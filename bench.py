@@ -261,6 +261,9 @@ def breakdown(wl, fwd_ms, bwd_ms):
     im2w = image_warp(wl.im2, ffw)
     g3 = torch.randn_like(im2w)
     rows = [("corr_fwd", fwd_ms, CORR_FWD_BYTES * B), ("corr_bwd", bwd_ms, CORR_BWD_BYTES * B)]
+    fah, fbh = wl.fa.half(), wl.fb.half()
+    rows.append(("corr_fwd, fp16 storage / f32 accumulate (extension)", timeit(lambda: ops.correlation_fp16(fah, fbh)),
+                 CORR_FWD_BYTES * B // 2))
     rows.append(("image_warp C3", timeit(lambda: image_warp(wl.im2, ffw)), npx * 32))
     rows.append(("image_warp C2", timeit(lambda: image_warp(fbw, ffw)), npx * 24))
     rows.append(("image_warp_grad flow C3", timeit(lambda: image_warp_grad(g3, wl.im2, ffw, False, True)), npx * 40))

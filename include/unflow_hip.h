@@ -192,6 +192,17 @@ int unflow_gradient_loss_bwd(const float *im1, const float *im2_warped, const fl
 int unflow_gradient_delta(const float *im1, const float *im2_warped, float *diff, int B, int H, int W,
                           unflow_stream_t stream);
 
+/* ---------------------------------------------------------------- fp16 storage (extension)
+ * NOT in the reference (float32 only; BASELINE config 5 names "fp16 with fp32 accumulate").
+ * Forward correlation with half-precision tensors in HBM: in0, in1 [B,C,H,W] and out
+ * [B,441,H,W] are IEEE binary16; they are widened to f32 on the way into LDS, multiplied
+ * and accumulated in f32 (every product exact) and rounded to half once on output.
+ * FlowNetC attributes only (kernel_size 1, max_displacement = pad = 20, stride_1 1,
+ * stride_2 2), W % 4 == 0, 8-byte aligned tensors; otherwise UNFLOW_ERR_INVALID_ARGUMENT. */
+int unflow_correlation_fwd_f16(const void *in0, const void *in1, void *out, int B, int C, int H, int W,
+                               int kernel_size, int max_displacement, int pad, int stride_1,
+                               int stride_2, unflow_stream_t stream);
+
 /* ---------------------------------------------------------------- integer census (extension)
  * NOT in the reference (its census is the soft one above).  Classical ternary
  * census on I = 255*gray(im), window (2*max_distance+1)^2, zero padding:

@@ -195,6 +195,32 @@ def test_correlation_adversarial_cancellation(oracle_mod, dev):
     assert np.abs(got - want).max() <= 1e-5 * scale
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 16, 24), (1, 256, 16, 16), (1, 7, 12, 20), (2, 20, 50, 36)])
+def test_correlation_fp16_storage(oracle_mod, dev, shape):
+    """Extension (BASELINE config 5 wording "fp16 with fp32 accumulate"; not in the reference):
+    half tensors in HBM, f32 products and sums.  Against the fp32 oracle on the SAME
+    half-rounded inputs the only differences are the f32 summation order and the one
+    rounding of the result to half: within one half-ulp (SURVEY 8d asks for rtol 2e-3)."""
+    from unflow_amd import ops
+    rng = np.random.default_rng(sum(shape))
+    f0 = rng.standard_normal(shape).astype(np.float16)
+    f1 = rng.standard_normal(shape).astype(np.float16)
+    want32, _, _ = oracle_mod.correlation(f0.astype(np.float32), f1.astype(np.float32))
+    want = want32.astype(np.float16)
+    got = ops.correlation_fp16(torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev))
+    assert got.dtype == torch.float16 and tuple(got.shape) == want.shape
+    g = got.cpu().numpy()
+    np.testing.assert_allclose(g.astype(np.float32), want.astype(np.float32), rtol=2e-3, atol=1e-6)
+    assert (g == want).mean() > 0.99            # all but the results that sit on a rounding boundary are identical
+    # and against the fp32 kernel on the widened inputs, rounded the same way
+    ref = ops.correlation(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1.astype(np.float32)).to(dev))
+    assert (got == ref.half()).float().mean() > 0.99
+    with pytest.raises(ValueError, match="FlowNetC"):
+        ops.correlation_fp16(torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev), max_displacement=4, pad=4)
+    with pytest.raises(TypeError):
+        ops.correlation_fp16(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1).to(dev))
+
+
 def test_correlation_errors(dev):
     from unflow_amd import ops
     f = torch.zeros((1, 1, 4, 4), device=dev)

@@ -438,11 +438,74 @@ struct FwdStagerH {
   }
 };
 
-template <int VEC>
-__global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(const float *__restrict__ in0,
-                                                                         const float *__restrict__ in1,
-                                                                         float *__restrict__ out, int C, int H,
-                                                                         int W, int nbx, int nby) {
+// fp16 STORAGE (extension, not in the reference): the operands are half in HBM and are
+// converted to f32 on their way into the same LDS images, so the MFMA loop -- f32 inputs,
+// f32 accumulation, every product exact -- is unchanged.  LDS-DMA cannot convert, so the
+// next chunk is fetched into registers (8-byte loads of 4 halves, range-checked by the
+// buffer descriptor) at the start of a chunk and converted + written to LDS at its end.
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+struct FwdStagerH16 {
+  static constexpr int F1_ROUNDS = (PLANEH / 4 + 63) / 64;   // 4 rounds of 64 lanes x 4 halves (last one half)
+  unsigned voff1[F1_ROUNDS], voff0;
+  i32x2 r1[F1_ROUNDS], r0v;
+  int wave, lane;
+  __amdgpu_buffer_rsrc_t rs0, rs1;
+
+  __device__ inline void init(int H, int W, int cy, int ys0, int xs0, int wrow0) {
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __builtin_assume(wave >= 0 && wave < NWAVES);
+    lane = threadIdx.x & 63;
+    const long long plane = (long long)H * W;
+#pragma unroll
+    for (int j = 0; j < F1_ROUNDS; ++j) {
+      const int f = (j * 64 + lane) * 4;
+      const int row = f / ROWF, x = f - row * ROWF;
+      const int Y = S * (ys0 - R + wrow0 + row) + cy, X = S * (xs0 - R) + x;
+      const bool in = f < PLANEH && Y >= 0 && Y < H && X >= 0 && X < W;   // X, W multiples of 4: all or nothing
+      voff1[j] = in ? (unsigned)((wave * plane + (long long)Y * W + X) * 2) : OOB;
+    }
+    const int f = (int)threadIdx.x * 4;                                   // float inside the f0 image [c][row][x]
+    const int c = f / F0PL, r = f - c * F0PL, row = r / RW, x = r - row * RW;
+    const int Y = S * (ys0 + row) + cy, X = S * xs0 + x;
+    const bool in = f < F0_STAGE && Y >= 0 && Y < H && X >= 0 && X < W;
+    voff0 = in ? (unsigned)((c * plane + (long long)Y * W + X) * 2) : OOB;
+  }
+  __device__ inline void bind(const _Float16 *in0, const _Float16 *in1, long long item, int c0, int C, long long plane) {
+    const int bytes = (int)((long long)(C - c0) * plane * 2);
+    rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(in0 + (item * C + c0) * plane), (short)0, bytes, 0x00020000);
+    rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16 *>(in1 + (item * C + c0) * plane), (short)0, bytes, 0x00020000);
+  }
+  __device__ inline void load() {
+#pragma unroll
+    for (int j = 0; j < F1_ROUNDS; ++j) r1[j] = __builtin_amdgcn_raw_buffer_load_b64(rs1, (int)voff1[j], 0, 0);
+    r0v = __builtin_amdgcn_raw_buffer_load_b64(rs0, (int)voff0, 0, 0);
+  }
+  __device__ inline void store(float *stage) const {
+#pragma unroll
+    for (int j = 0; j < F1_ROUNDS; ++j) {
+      const int f = (j * 64 + lane) * 4;
+      if (f < PLANEH) {
+        const f16x4 h = __builtin_bit_cast(f16x4, r1[j]);
+        float *dst = stage + wave * PLSH + (wave & 1) + f;
+        dst[0] = (float)h.x; dst[1] = (float)h.y; dst[2] = (float)h.z; dst[3] = (float)h.w;
+      }
+    }
+    const int f = (int)threadIdx.x * 4;
+    if (f < F0_STAGE) {
+      const f16x4 h = __builtin_bit_cast(f16x4, r0v);
+      float *dst = stage + F1_STAGEH + f;
+      dst[0] = (float)h.x; dst[1] = (float)h.y; dst[2] = (float)h.z; dst[3] = (float)h.w;
+    }
+  }
+};
+
+template <int VEC, bool F16>
+__global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
+    const std::conditional_t<F16, _Float16, float> *__restrict__ in0,
+    const std::conditional_t<F16, _Float16, float> *__restrict__ in1,
+    std::conditional_t<F16, _Float16, float> *__restrict__ out, int C, int H, int W, int nbx, int nby) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int cx = wave & 1, tx = (wave >> 1) & 1, ty = wave >> 2;
@@ -475,22 +538,29 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(const f
     }
   }
 
-  using St = FwdStagerH<VEC>;
+  using St = std::conditional_t<F16, FwdStagerH16, FwdStagerH<VEC>>;
   St st;
   st.init(H, W, cy, ys0, xs0, 4 * TQH * half);
   const long long plane = (long long)H * W;
   const int nchunks = (C + KC - 1) / KC;
   st.bind(in0, in1, item, 0, C, plane);
-  st.template issue_range<0, St::PER_WAVE>(lds);
+  if constexpr (F16) {
+    st.load();
+    st.store(lds);
+  } else {
+    st.template issue_range<0, St::PER_WAVE>(lds);
+  }
   __syncthreads();
 
   constexpr int GROUPS = (KC / 4) * TQH;                             // 6 MFMA groups per chunk
-  constexpr int PER_GROUP = (2 * St::PER_WAVE + GROUPS - 1) / GROUPS; // all DMA in the first K-step
   for (int ch = 0; ch < nchunks; ++ch) {
     const float *cur = lds + (ch & 1) * STAGEH;
     float *nxt = lds + ((ch + 1) & 1) * STAGEH;
     const bool more = ch + 1 < nchunks;
-    if (more) st.bind(in0, in1, item, (ch + 1) * KC, C, plane);
+    if (more) {
+      st.bind(in0, in1, item, (ch + 1) * KC, C, plane);
+      if constexpr (F16) st.load();            // lands in registers while this chunk computes
+    }
 #pragma unroll
     for (int kk = 0; kk < KC / 4; ++kk) {
       const float a = cur[a_off + kk * 4 * F0PL];
@@ -506,13 +576,19 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(const f
           for (int t = g * TQ; t < (g + 1) * TQ; ++t)
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
         }
-        if (more) {
-          if (kk == 0) st.template issue_range<g * PER_GROUP, PER_GROUP>(nxt);
-          else st.template issue_range<(TQH + g) * PER_GROUP, PER_GROUP>(nxt);
+        if constexpr (!F16) {
+          constexpr int PER_GROUP = (2 * St::PER_WAVE + GROUPS - 1) / GROUPS;   // all DMA in the first K-step
+          if (more) {
+            if (kk == 0) st.template issue_range<g * PER_GROUP, PER_GROUP>(nxt);
+            else st.template issue_range<(TQH + g) * PER_GROUP, PER_GROUP>(nxt);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       };
       group(Int<0>{}); group(Int<1>{}); group(Int<2>{});
+    }
+    if constexpr (F16) {
+      if (more) st.store(nxt);
     }
     __syncthreads();
   }
@@ -586,8 +662,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(const f
         if (y >= H || x >= W) continue;
         const float *src = ob + (r * RW + c4 * 4) * (SLAB_DYH * GW) + ddl * GW + dxx;
         const float4 v = make_float4(src[0], src[SLAB_DYH * GW], src[2 * SLAB_DYH * GW], src[3 * SLAB_DYH * GW]);
-        float *dst = out + (item * D + d) * plane + (long long)y * W + x;
-        if (x + 3 < W && (W & 3) == 0) {
+        auto *dst = out + (item * D + d) * plane + (long long)y * W + x;
+        if constexpr (F16) {   // W % 4 == 0 and an 8-byte aligned base are preconditions of this variant
+          *reinterpret_cast<f16x4 *>(dst) = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        } else if (x + 3 < W && (W & 3) == 0) {
           *reinterpret_cast<float4 *>(dst) = v;
         } else {
           dst[0] = v.x;
@@ -924,8 +1002,8 @@ int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, 
   const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1);
   if (wide) {   // two half-window workgroups per region, two workgroups per CU: 0.76 -> 0.66 ms at B=32
     const size_t smem2 = sizeof(float) * 2 * STAGEH;
-    if (int rc = reserve_lds<corr_mfma_fwd_half_kernel<4>>(smem2, "correlation_fwd (mfma, half windows)")) return rc;
-    hipLaunchKernelGGL(corr_mfma_fwd_half_kernel<4>, dim3(grid.x * 2), dim3(NTHREADS), smem2, s, in0, in1, out, C, H, W,
+    if (int rc = reserve_lds<corr_mfma_fwd_half_kernel<4, false>>(smem2, "correlation_fwd (mfma, half windows)")) return rc;
+    hipLaunchKernelGGL((corr_mfma_fwd_half_kernel<4, false>), dim3(grid.x * 2), dim3(NTHREADS), smem2, s, in0, in1, out, C, H, W,
                        nbx, nby);
     return launch_status("correlation_fwd (mfma, half windows)");
   }
@@ -933,6 +1011,22 @@ int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, 
   if (int rc = reserve_lds<corr_mfma_fwd_kernel<1>>(smem, "correlation_fwd (mfma)")) return rc;
   hipLaunchKernelGGL(corr_mfma_fwd_kernel<1>, grid, dim3(NTHREADS), smem, s, in0, in1, out, C, H, W, nbx, nby);
   return launch_status("correlation_fwd (mfma)");
+}
+
+int corr_mfma_fwd_f16(const void *in0, const void *in1, void *out, int B, int C, const CorrGeometry &g,
+                      hipStream_t s) {
+  const int H = g.H, W = g.W;
+  const int hs = (H + S - 1) / S, ws = (W + S - 1) / S;
+  const int nbx = (ws + RX - 1) / RX, nby = (hs + RY - 1) / RY;
+  auto al8 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  if ((W % 4) != 0 || !al8(in0) || !al8(in1) || !al8(out))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation (fp16 storage): W must be a multiple of 4 and the tensors 8-byte aligned");
+  const size_t smem = sizeof(float) * 2 * STAGEH;
+  if (int rc = reserve_lds<corr_mfma_fwd_half_kernel<4, true>>(smem, "correlation_fwd (fp16 storage)")) return rc;
+  hipLaunchKernelGGL((corr_mfma_fwd_half_kernel<4, true>), dim3(nbx * nby * B * S * 2), dim3(NTHREADS), smem, s,
+                     static_cast<const _Float16 *>(in0), static_cast<const _Float16 *>(in1), static_cast<_Float16 *>(out), C,
+                     H, W, nbx, nby);
+  return launch_status("correlation_fwd (fp16 storage)");
 }
 
 int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,

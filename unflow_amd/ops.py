@@ -218,6 +218,27 @@ def correlation(first, second, kernel_size=1, max_displacement=20, pad=20, strid
     return _Correlation.apply(first, second, kernel_size, max_displacement, pad, stride_1, stride_2)
 
 
+def correlation_fp16(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
+    """Extension (not in the reference, whose ops are float32 only): ``correlation`` on
+    half-precision tensors -- fp16 in HBM, f32 products and accumulation, one rounding to
+    half on output.  FlowNetC attributes only; forward only."""
+    for name, t in (("first", first), ("second", second)):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float16:
+            raise TypeError("%s must be a float16 CUDA/HIP tensor" % name)
+    first, second = first.contiguous(), second.contiguous()
+    _require_rank4(first, "first")
+    if first.shape != second.shape:
+        raise ValueError("Input shapes have to be the same")
+    B, C, H, W = first.shape
+    shapes = correlation_output_shape(first.shape, kernel_size, max_displacement, pad, stride_1, stride_2)
+    out = torch.empty(shapes["correlation"], device=first.device, dtype=torch.float16)
+    with torch.cuda.device(first.device):
+        _lib.check(_lib.load().unflow_correlation_fwd_f16(
+            ctypes.c_void_p(first.data_ptr()), ctypes.c_void_p(second.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+            B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, _stream()))
+    return out
+
+
 def correlation_with_padded(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1,
                             stride_2=2):
     """All three outputs of the reference op (``_correlation_module.correlation``):
