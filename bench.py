@@ -264,6 +264,10 @@ def breakdown(wl, fwd_ms, bwd_ms):
     fah, fbh = wl.fa.half(), wl.fb.half()
     rows.append(("corr_fwd, fp16 storage / f32 accumulate (extension)", timeit(lambda: ops.correlation_fp16(fah, fbh)),
                  CORR_FWD_BYTES * B // 2))
+    toph = wl.top_fw.half()
+    rows.append(("corr_bwd, fp16 storage / f32 accumulate (extension)",
+                 timeit(lambda: ops.correlation_fp16_grad(toph, fah, fbh)), CORR_BWD_BYTES * B // 2))
+    del toph, fah, fbh
     rows.append(("image_warp C3", timeit(lambda: image_warp(wl.im2, ffw)), npx * 32))
     rows.append(("image_warp C2", timeit(lambda: image_warp(fbw, ffw)), npx * 24))
     rows.append(("image_warp_grad flow C3", timeit(lambda: image_warp_grad(g3, wl.im2, ffw, False, True)), npx * 40))

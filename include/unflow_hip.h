@@ -194,7 +194,7 @@ int unflow_gradient_delta(const float *im1, const float *im2_warped, float *diff
 
 /* ---------------------------------------------------------------- fp16 storage (extension)
  * NOT in the reference (float32 only; BASELINE config 5 names "fp16 with fp32 accumulate").
- * Forward correlation with half-precision tensors in HBM: in0, in1 [B,C,H,W] and out
+ * Correlation with half-precision tensors in HBM: in0, in1 [B,C,H,W] and out
  * [B,441,H,W] are IEEE binary16; they are widened to f32 on the way into LDS, multiplied
  * and accumulated in f32 (every product exact) and rounded to half once on output.
  * FlowNetC attributes only (kernel_size 1, max_displacement = pad = 20, stride_1 1,
@@ -202,6 +202,12 @@ int unflow_gradient_delta(const float *im1, const float *im2_warped, float *diff
 int unflow_correlation_fwd_f16(const void *in0, const void *in1, void *out, int B, int C, int H, int W,
                                int kernel_size, int max_displacement, int pad, int stride_1,
                                int stride_2, unflow_stream_t stream);
+/* Its gradients: topdiff [B,441,H,W], in0, in1, g0, g1 [B,C,H,W], all binary16; f32
+ * products and sums, one rounding to half per output element. */
+int unflow_correlation_bwd_f16(const void *topdiff, const void *in0, const void *in1, void *g0,
+                               void *g1, int B, int C, int H, int W, int kernel_size,
+                               int max_displacement, int pad, int stride_1, int stride_2,
+                               unflow_stream_t stream);
 
 /* ---------------------------------------------------------------- integer census (extension)
  * NOT in the reference (its census is the soft one above).  Classical ternary

@@ -143,8 +143,8 @@ def test_census_properties_cfg3(dev):
 
 
 def test_cfg5_shapes_fp32(dev):
-    """BASELINE config 5's shapes (768x1280, batch 16, features [16,256,96,160]) in fp32 --
-    the fp16-storage variant it names is not in the reference and not built.
+    """BASELINE config 5's shapes (768x1280, batch 16, features [16,256,96,160]) in fp32 and,
+    for the correlation, with fp16 storage (extension; the reference is float32 only).
     Correlation: adjoint identity and zero-displacement plane; forward_warp: splat mass;
     stacked-net block: zero flow reproduces [im1, im2, 0, im2, |im2 - im1|]."""
     from unflow_amd import flownet, ops
@@ -162,7 +162,13 @@ def test_cfg5_shapes_fp32(dev):
         rhs = (gg.double() * df.double()).sum()
         scale = float(gg.double().norm() * df.double().norm())
         assert abs(float(lhs) - float(rhs)) <= 1e-6 * scale, (float(lhs), float(rhs), scale)
-    del c, top, g0, g1, df, f0, f1
+    # fp16 storage at the same shape: equals the f32 kernel on the widened inputs up to the final rounding
+    h0, h1 = f0.half(), f1.half()
+    ch = ops.correlation_fp16(h0, h1)
+    ref = ops.correlation(h0.float(), h1.float()).half()
+    assert (ch == ref).float().mean() > 0.99
+    torch.testing.assert_close(ch.float(), ref.float(), rtol=2e-3, atol=1e-6)
+    del c, top, g0, g1, df, f0, f1, h0, h1, ch, ref
     flow = torch.zeros((16, 768, 1280, 2), device=dev)
     out = ops.forward_warp(flow)
     np.testing.assert_allclose(float(out[:, 10:-10, 10:-10].min()), 6.2831479, rtol=1e-6)

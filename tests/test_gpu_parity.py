@@ -215,6 +215,18 @@ def test_correlation_fp16_storage(oracle_mod, dev, shape):
     # and against the fp32 kernel on the widened inputs, rounded the same way
     ref = ops.correlation(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1.astype(np.float32)).to(dev))
     assert (got == ref.half()).float().mean() > 0.99
+    # gradients: oracle on the half-rounded top / inputs, rounded to half
+    top = rng.standard_normal(want.shape).astype(np.float16)
+    _, p0, p1 = oracle_mod.correlation(f0.astype(np.float32), f1.astype(np.float32))
+    w0, w1 = oracle_mod.correlation_grad(top.astype(np.float32), f0.astype(np.float32), f1.astype(np.float32), p0, p1)
+    a = torch.from_numpy(f0).to(dev).requires_grad_(True)
+    b = torch.from_numpy(f1).to(dev).requires_grad_(True)
+    ops.correlation_fp16(a, b).backward(torch.from_numpy(top).to(dev))
+    for gg, ww in ((a.grad, w0), (b.grad, w1)):
+        assert gg.dtype == torch.float16
+        gnp, wh = gg.cpu().numpy(), ww.astype(np.float16)
+        np.testing.assert_allclose(gnp.astype(np.float32), wh.astype(np.float32), rtol=2e-3, atol=2e-4 * np.abs(ww).max())
+        assert (gnp == wh).mean() > 0.98
     with pytest.raises(ValueError, match="FlowNetC"):
         ops.correlation_fp16(torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev), max_displacement=4, pad=4)
     with pytest.raises(TypeError):

@@ -23,6 +23,8 @@ int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, 
 // fp16 storage, f32 accumulation (extension): half in, half out
 int corr_mfma_fwd_f16(const void *in0, const void *in1, void *out, int B, int C, const CorrGeometry &g,
                       hipStream_t s);
+int corr_mfma_bwd_f16(const void *topdiff, const void *in0, const void *in1, void *g0, void *g1, int B, int C,
+                      const CorrGeometry &g, hipStream_t s);
 int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,
                   const CorrGeometry &g, hipStream_t s);
 

@@ -243,6 +243,20 @@ extern "C" int unflow_correlation_fwd_f16(const void *in0, const void *in1, void
   return corr_mfma_fwd_f16(in0, in1, out, B, C, g, as_stream(stream));
 }
 
+extern "C" int unflow_correlation_bwd_f16(const void *topdiff, const void *in0, const void *in1, void *g0, void *g1,
+                                          int B, int C, int H, int W, int kernel_size, int max_displacement,
+                                          int pad, int stride_1, int stride_2, unflow_stream_t stream) {
+  CorrGeometry g;
+  if (int rc = corr_geometry_init(&g, H, W, kernel_size, max_displacement, pad, stride_1, stride_2)) return rc;
+  if (B < 0 || C < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation_grad: negative dimension");
+  if ((long long)B * C * H * W == 0) return UNFLOW_OK;
+  if (!corr_mfma_bwd_supported(g, C))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT,
+                "correlation_grad (fp16 storage) is implemented for the FlowNetC attributes only "
+                "(kernel_size 1, max_displacement 20, pad 20, stride_1 1, stride_2 2)");
+  return corr_mfma_bwd_f16(topdiff, in0, in1, g0, g1, B, C, g, as_stream(stream));
+}
+
 extern "C" int unflow_correlation_bwd(const float *topdiff, const float *in0, const float *in1,
                                       const float *padded0, const float *padded1, float *g0, float *g1, int B,
                                       int C, int H, int W, int kernel_size, int max_displacement, int pad,

@@ -721,11 +721,16 @@ constexpr int SW_LDS = 2 * SW_STAGE + SW_OUT;   // 37888 floats = 148 KB
 constexpr int KSTEPS = WIN / 4;                 // 6 K-steps per window row and tile
 constexpr int RING = 3;                         // live tiles per wave
 
-template <int VA, int VT, bool WRT1, bool FULL>
-__global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float *__restrict__ topdiff,
-                                                                    const float *__restrict__ fin,
-                                                                    float *__restrict__ gout, int C, int H, int W,
-                                                                    int nbx, int nch) {
+template <int VA, int VT, bool WRT1, bool FULL, bool F16 = false>
+__global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
+    const std::conditional_t<F16, _Float16, float> *__restrict__ topdiff,
+    const std::conditional_t<F16, _Float16, float> *__restrict__ fin,
+    std::conditional_t<F16, _Float16, float> *__restrict__ gout, int C, int H, int W, int nbx, int nch) {
+  // F16 (extension): half tensors in HBM.  The row is fetched into registers (8-byte loads of
+  // 4 halves, same piece layout as the DMA) while the previous row computes, and widened to
+  // f32 into the LDS stage before the barrier; the MFMA loop is the f32 one.
+  static_assert(!F16 || (VA == 4 && VT == 4), "fp16 storage uses the 4-element pieces");
+  constexpr int ES = F16 ? 2 : 4;              // bytes per element in HBM
   // WRT1 = false: gradient wrt input 0 (fin = input 1); true: wrt input 1 (fin = input 0).
   // FULL: every channel group holds 128 channels (C % 128 == 0), so no MFMA needs a
   // guard (a guard per MFMA costs three scalar instructions, 432 per window row).
@@ -765,10 +770,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
   const int c0 = chg * CWS;
   const int nmt = min(MTS, (C - c0 + 15) / 16);
   const long long plane = (long long)H * W;
-  const __amdgpu_buffer_rsrc_t rtop = make_rsrc(topdiff + item * (GW * GW) * plane, (unsigned)(GW * GW * plane * 4));
-  const __amdgpu_buffer_rsrc_t rin =
-      make_rsrc(fin + (item * C + c0) * plane, (unsigned)((long long)(C - c0) * plane * 4));
-  const int row_bytes = S * W * 4;             // one class row further down
+  const __amdgpu_buffer_rsrc_t rtop = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<std::conditional_t<F16, _Float16, float> *>(topdiff + item * (GW * GW) * plane), (short)0,
+      (int)(GW * GW * plane * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<std::conditional_t<F16, _Float16, float> *>(fin + (item * C + c0) * plane), (short)0,
+      (int)((long long)(C - c0) * plane * ES), 0x00020000);
+  const int row_bytes = S * W * ES;            // one class row further down
 
   const int k = lane >> 4, n = lane & 15;
   const int oyl = n >> 2, oxl = n & 3;
@@ -785,7 +793,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
     const int f = ((wave + NWAVES * j) * 64 + lane) * VA;
     const int c = f / ACS, x = f - c * ACS;
     const int X = S * (xs0 - R) + x;
-    a_voff[j] = (f < SA_STAGE && x < ROWF && X >= 0 && X < W && c0 + c < C) ? (unsigned)((c * plane + X) * 4) : OOB;
+    a_voff[j] = (f < SA_STAGE && x < ROWF && X >= 0 && X < W && c0 + c < C) ? (unsigned)((c * plane + X) * ES) : OOB;
   }
   int t_base[T_PER_WAVE];      // byte offset of the segment at sweep row 0
   int t_orow[T_PER_WAVE];      // row of the top image (output row = w - R + orow); huge = never valid
@@ -805,7 +813,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
       Xt = S * xs0 + col;
     }
     const bool ok = wave + NWAVES * j < T_PIECES && f < ST_IMAGE && Xt + VT - 1 >= 0 && Xt < W;
-    t_base[j] = (int)((((long long)(dyp * GW + dxp) * H + Y0) * W + Xt) * 4);
+    t_base[j] = (int)((((long long)(dyp * GW + dxp) * H + Y0) * W + Xt) * ES);
     t_orow[j] = ok ? orow : (1 << 28);
   }
   int b_dx[KSTEPS];            // LDS offset of dx' for K-step s (clamped), validity in b_dxok
@@ -828,7 +836,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
   // interleaved with the K-steps of the previous row.
   auto issue_slice = [&](auto SL, int w, float *stage) {
     constexpr int sl = decltype(SL)::value;
-    const int soff = (S * w + cy) * W * 4;     // row w is always inside the image
+    const int soff = (S * w + cy) * W * ES;    // row w is always inside the image
 #pragma unroll
     for (int j = sl * APS; j < (sl + 1) * APS; ++j) {
       if (j < A_PER_WAVE && wave + NWAVES * j < A_PIECES)
@@ -849,6 +857,37 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
     issue_slice(Int<3>{}, w, stage); issue_slice(Int<4>{}, w, stage); issue_slice(Int<5>{}, w, stage);
   };
 
+  // fp16 storage: the same pieces through registers
+  i32x2 ra[F16 ? A_PER_WAVE : 1], rt[F16 ? T_PER_WAVE : 1];
+  auto load_row = [&](int w) {
+    if constexpr (F16) {
+      const int soff = (S * w + cy) * W * ES;
+#pragma unroll
+      for (int j = 0; j < A_PER_WAVE; ++j)
+        ra[j] = (wave + NWAVES * j < A_PIECES) ? __builtin_amdgcn_raw_buffer_load_b64(rin, (int)a_voff[j], soff, 0) : i32x2{0, 0};
+#pragma unroll
+      for (int j = 0; j < T_PER_WAVE; ++j) {
+        const int oy = w - R + t_orow[j];
+        const unsigned voff = (oy >= 0 && oy < hs) ? (unsigned)(t_base[j] + w * row_bytes) : OOB;
+        rt[j] = (wave + NWAVES * j < T_PIECES) ? __builtin_amdgcn_raw_buffer_load_b64(rtop, (int)voff, 0, 0) : i32x2{0, 0};
+      }
+    }
+  };
+  auto store_row = [&](float *stage) {
+    if constexpr (F16) {
+      auto put = [&](float *dst, i32x2 raw) {
+        const f16x4 h = __builtin_bit_cast(f16x4, raw);
+        *reinterpret_cast<f32x4 *>(dst) = f32x4{(float)h.x, (float)h.y, (float)h.z, (float)h.w};
+      };
+#pragma unroll
+      for (int j = 0; j < A_PER_WAVE; ++j)
+        if (wave + NWAVES * j < A_PIECES) put(stage + (wave + NWAVES * j) * A_PIECE + lane * VA, ra[j]);
+#pragma unroll
+      for (int j = 0; j < T_PER_WAVE; ++j)
+        if (wave + NWAVES * j < T_PIECES) put(stage + SA_STAGE + (wave + NWAVES * j) * T_PIECE + lane * VT, rt[j]);
+    }
+  };
+
   // Tile t = 2u + ph of this wave's parity lives in ring slot u % 3 while
   // 4t - 10 <= w <= 4t + 13.
   auto tile_in_slot = [&](int slot, int w) -> int {
@@ -859,12 +898,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
     return (u >= 0 && t < ntiles && w <= 4 * t + TP - 1 + R) ? t : -1;
   };
 
-  issue_row(0, lds);
+  if constexpr (F16) {
+    load_row(0);
+    store_row(lds);
+  } else {
+    issue_row(0, lds);
+  }
   __syncthreads();
   for (int w = 0; w < hs; ++w) {
     const float *cur = lds + (w & 1) * SW_STAGE;
     float *nxt = lds + ((w + 1) & 1) * SW_STAGE;
     const bool more = w + 1 < hs;
+    if (F16 && more) load_row(w + 1);
     // per ring slot: live tile, LDS row offset of the top image row that pairs
     // (w, this lane's output row), validity
     int tile[RING], b_row[RING];
@@ -902,11 +947,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
               acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s4 & 1][m], b, acc[sl][m], 0, 0, 0);
         }
       }
-      if (more) issue_slice(S4, w + 1, nxt);
+      if (!F16 && more) issue_slice(S4, w + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
     };
     load_ab(Int<0>{});
     kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
+    if (F16 && more) store_row(nxt);
     __syncthreads();
 
     // ---- tiles whose last window row was w: regroup through LDS to
@@ -951,8 +997,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(const float 
         } else {
           v.x /= (float)C; v.y /= (float)C; v.z /= (float)C; v.w /= (float)C;
         }
-        float *dst = gout + (item * C + c) * plane + (long long)y * W + x;
-        if (x + 3 < W && (W & 3) == 0) {
+        auto *dst = gout + (item * C + c) * plane + (long long)y * W + x;
+        if constexpr (F16) {   // W % 4 == 0 and 8-byte aligned tensors are preconditions of this variant
+          *reinterpret_cast<f16x4 *>(dst) = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        } else if (x + 3 < W && (W & 3) == 0) {
           *reinterpret_cast<float4 *>(dst) = v;
         } else {
           dst[0] = v.x;
@@ -1053,6 +1101,32 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
   else UNFLOW_LAUNCH(1, 1, false);
 #undef UNFLOW_LAUNCH
   return launch_status("correlation_bwd (mfma)");
+}
+
+int corr_mfma_bwd_f16(const void *topdiff, const void *in0, const void *in1, void *g0, void *g1, int B, int C,
+                      const CorrGeometry &g, hipStream_t s) {
+  const int H = g.H, W = g.W;
+  const int ws = (W + S - 1) / S;
+  const int nbx = (ws + RX - 1) / RX, nch = (C + CWS - 1) / CWS;
+  auto al8 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  if ((W % 4) != 0 || !al8(topdiff) || !al8(in0) || !al8(in1) || !al8(g0) || !al8(g1))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation_grad (fp16 storage): W must be a multiple of 4 and the tensors 8-byte aligned");
+  const dim3 grid(nbx * nch * S * B);
+  const size_t smem = sizeof(float) * SW_LDS;
+  using H16 = _Float16;
+#define UNFLOW_LAUNCH16(FULL)                                                                                       \
+  do {                                                                                                              \
+    if (int rc = reserve_lds<corr_mfma_bwd_kernel<4, 4, false, FULL, true>>(smem, "correlation_bwd (fp16 storage)")) return rc; \
+    if (int rc = reserve_lds<corr_mfma_bwd_kernel<4, 4, true, FULL, true>>(smem, "correlation_bwd (fp16 storage)")) return rc;  \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<4, 4, false, FULL, true>), grid, dim3(NTHREADS), smem, s,               \
+                       static_cast<const H16 *>(topdiff), static_cast<const H16 *>(in1), static_cast<H16 *>(g0), C, H, W, nbx, nch); \
+    hipLaunchKernelGGL((corr_mfma_bwd_kernel<4, 4, true, FULL, true>), grid, dim3(NTHREADS), smem, s,                \
+                       static_cast<const H16 *>(topdiff), static_cast<const H16 *>(in0), static_cast<H16 *>(g1), C, H, W, nbx, nch); \
+  } while (0)
+  if ((C % CWS) == 0) UNFLOW_LAUNCH16(true);
+  else UNFLOW_LAUNCH16(false);
+#undef UNFLOW_LAUNCH16
+  return launch_status("correlation_bwd (fp16 storage)");
 }
 
 }  // namespace unflow

@@ -218,25 +218,62 @@ def correlation(first, second, kernel_size=1, max_displacement=20, pad=20, strid
     return _Correlation.apply(first, second, kernel_size, max_displacement, pad, stride_1, stride_2)
 
 
+def _half(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float16:
+        raise TypeError("%s must be a float16 CUDA/HIP tensor" % name)
+    return t.contiguous()
+
+
+def _hp(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _CorrelationFP16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, first, second, attrs):
+        first, second = _half(first, "first"), _half(second, "second")
+        _require_rank4(first, "first")
+        if first.shape != second.shape:
+            raise ValueError("Input shapes have to be the same")
+        B, C, H, W = first.shape
+        shapes = correlation_output_shape(first.shape, *attrs)
+        out = torch.empty(shapes["correlation"], device=first.device, dtype=torch.float16)
+        with torch.cuda.device(first.device):
+            _lib.check(_lib.load().unflow_correlation_fwd_f16(_hp(first), _hp(second), _hp(out), B, C, H, W,
+                                                              *attrs, _stream()))
+        ctx.save_for_backward(first, second)
+        ctx.attrs = attrs
+        return out
+
+    @staticmethod
+    def backward(ctx, in_grad):
+        first, second = ctx.saved_tensors
+        g0, g1 = correlation_fp16_grad(in_grad, first, second, *ctx.attrs)
+        return g0, g1, None
+
+
+def correlation_fp16_grad(in_grad, original_input_0, original_input_1, kernel_size=1, max_displacement=20,
+                          pad=20, stride_1=1, stride_2=2):
+    """Gradients of ``correlation_fp16``: all tensors float16, f32 products and sums."""
+    in_grad = _half(in_grad, "input_grad")
+    in0, in1 = _half(original_input_0, "original_input_0"), _half(original_input_1, "original_input_1")
+    B, C, H, W = in0.shape
+    attrs = (kernel_size, max_displacement, pad, stride_1, stride_2)
+    shapes = correlation_output_shape(in0.shape, *attrs)
+    if tuple(in_grad.shape) != shapes["correlation"]:
+        raise ValueError("input_grad has shape %s, expected %s" % (tuple(in_grad.shape), shapes["correlation"]))
+    g0, g1 = torch.empty_like(in0), torch.empty_like(in0)
+    with torch.cuda.device(in0.device):
+        _lib.check(_lib.load().unflow_correlation_bwd_f16(_hp(in_grad), _hp(in0), _hp(in1), _hp(g0), _hp(g1),
+                                                          B, C, H, W, *attrs, _stream()))
+    return g0, g1
+
+
 def correlation_fp16(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
     """Extension (not in the reference, whose ops are float32 only): ``correlation`` on
     half-precision tensors -- fp16 in HBM, f32 products and accumulation, one rounding to
-    half on output.  FlowNetC attributes only; forward only."""
-    for name, t in (("first", first), ("second", second)):
-        if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float16:
-            raise TypeError("%s must be a float16 CUDA/HIP tensor" % name)
-    first, second = first.contiguous(), second.contiguous()
-    _require_rank4(first, "first")
-    if first.shape != second.shape:
-        raise ValueError("Input shapes have to be the same")
-    B, C, H, W = first.shape
-    shapes = correlation_output_shape(first.shape, kernel_size, max_displacement, pad, stride_1, stride_2)
-    out = torch.empty(shapes["correlation"], device=first.device, dtype=torch.float16)
-    with torch.cuda.device(first.device):
-        _lib.check(_lib.load().unflow_correlation_fwd_f16(
-            ctypes.c_void_p(first.data_ptr()), ctypes.c_void_p(second.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-            B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, _stream()))
-    return out
+    half on output; differentiable.  FlowNetC attributes only."""
+    return _CorrelationFP16.apply(first, second, (kernel_size, max_displacement, pad, stride_1, stride_2))
 
 
 def correlation_with_padded(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1,
