@@ -7,9 +7,11 @@ One "step" = one pass of the whole path over a batch of image pairs
   * FlowNetC correlation, both directions (core/flownet.py:35-43 runs it fw and
     bw): 2 forward calls on [B,256,H/8,W/8] and their 2 backward calls;
   * one level-0 ``compute_losses`` at full resolution, max_distance=3
-    (core/unsupervised.py:87-95): 4 image_warp, fb-occlusion masks, 2
-    forward_warp disocclusion maps, 2 soft-census ternary losses 7x7 with the
-    charbonnier reductions -- forward, then backward to dL/dflow_fw, dL/dflow_bw;
+    (core/unsupervised.py:87-95): the 4 image_warp (2 of the images; the 2 of the
+    flows are evaluated inside the fb-occlusion mask kernel, nothing else reads
+    them), fb-occlusion masks, 2 forward_warp disocclusion densities + the 'sym'
+    term, 2 soft-census ternary losses 7x7 with the charbonnier reductions --
+    forward, then backward to dL/dflow_fw, dL/dflow_bw;
   * with N>1 ranks: RCCL all-reduce of the loss scalar and of a 156.7 MB
     gradient buffer standing in for the FlowNetC weights.
 
