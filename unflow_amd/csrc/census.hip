@@ -654,7 +654,7 @@ inline unsigned ew_grid(long long n) {
 // backward with dldd as a third LDS image fits only two workgroups per CU at 16 rows and
 // is slower than the unpaired kernel, 0.47 vs 0.42 ms; 0.38 ms at 8 rows; 0.31 ms with
 // dldd read in place.)
-constexpr int kPairRowsFwd = 16;
+constexpr int kPairRowsFwd = 16;   // 12 measures the same, 8 and 24+ are slower (halo rows / occupancy)
 inline dim3 pair_grid(int r, int rows_per_wave, int B, int H, int W) {
   const int cols = 64 - 2 * r, rows = kPairWaves * rows_per_wave;
   return dim3((W + cols - 1) / cols, (H + rows - 1) / rows, B);
