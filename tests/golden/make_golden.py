@@ -224,6 +224,17 @@ def oracle_seeded():
     assert abs(l - ref) <= 1e-6 * abs(ref), (l, ref)
     out["gradient_loss"] = np.float64(l)
     out["gradient_loss_grad"] = oracle.gradient_loss_grad(im1, out["image_warp"], mask)
+
+    # extensions (defined by include/unflow_hip.h, not by the reference): integer ternary census,
+    # stacked-net warp block, fp16-storage correlation (fp32 oracle on half-rounded inputs)
+    s1, s2 = oracle.census_transform(im1, 3, 0.9), oracle.census_transform(out["image_warp"], 3, 0.9)
+    d, total = oracle.census_hamming(s1, s2, mask)
+    out.update(census_sig1=s1, census_dist=d, census_total=np.uint64(total))
+    flow_lr = (rng.standard_normal((2, 6, 8, 2)) * 0.2).astype(np.float32)
+    out.update(stacked_flow_lr=flow_lr, stacked_inputs=oracle.stacked_inputs(im1, im2, flow_lr))
+    h0, h1 = f0.astype(np.float16), f1.astype(np.float16)
+    ch, hp0, hp1 = oracle.correlation(h0.astype(np.float32), h1.astype(np.float32))
+    out.update(corr16_f0=h0, corr16_f1=h1, corr16_out=ch.astype(np.float16))
     return out
 
 

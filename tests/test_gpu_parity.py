@@ -153,6 +153,22 @@ def test_seeded_stencil_terms(seeded, dev):
     close(im2w.grad, want, 1e-4, 1e-5 * np.abs(want).max())
 
 
+def test_seeded_extensions(seeded, dev):
+    """Committed vectors of the extensions: integer census (bit-exact), stacked-net block, fp16 correlation."""
+    from unflow_amd import flownet, losses, ops
+    im1, im2w = T(seeded["im1"], dev), T(seeded["image_warp"], dev)
+    s1, s2 = losses.census_transform(im1, 3, 0.9), losses.census_transform(im2w, 3, 0.9)
+    np.testing.assert_array_equal(N(s1).view(np.uint64), seeded["census_sig1"])
+    dist, total = losses.census_hamming(s1, s2, T(seeded["border_mask"], dev))
+    np.testing.assert_array_equal(N(dist), seeded["census_dist"])
+    assert int(total) == int(seeded["census_total"])
+    close(flownet.stacked_inputs(im1, T(seeded["im2"], dev), T(seeded["stacked_flow_lr"], dev)), seeded["stacked_inputs"])
+    got = ops.correlation_fp16(torch.from_numpy(seeded["corr16_f0"]).to(dev), torch.from_numpy(seeded["corr16_f1"]).to(dev))
+    g, w = got.cpu().numpy(), seeded["corr16_out"]
+    np.testing.assert_allclose(g.astype(np.float32), w.astype(np.float32), rtol=2e-3, atol=1e-6)
+    assert (g == w).mean() > 0.99
+
+
 # ----------------------------------------------------------------------------- fresh inputs vs oracle
 @pytest.mark.parametrize("shape,attrs", [
     ((2, 32, 16, 24), dict()),                                   # FlowNetC attrs

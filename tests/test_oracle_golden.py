@@ -246,3 +246,6 @@ def test_seeded_fixture_is_reproducible(seeded, oracle_mod):
     np.testing.assert_allclose(oracle_mod.smoothness_loss(seeded["flow"], 2), float(seeded["smooth_loss_o2"]), rtol=1e-7)
     np.testing.assert_array_equal(oracle_mod.gradient_loss_grad(seeded["im1"], seeded["image_warp"], seeded["border_mask"]),
                                   seeded["gradient_loss_grad"])
+    np.testing.assert_array_equal(oracle_mod.census_transform(seeded["im1"], 3, 0.9), seeded["census_sig1"])
+    np.testing.assert_array_equal(oracle_mod.stacked_inputs(seeded["im1"], seeded["im2"], seeded["stacked_flow_lr"]),
+                                  seeded["stacked_inputs"])
