@@ -125,6 +125,16 @@ int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped, const flo
                             const float *gout, float *d_im2_warped, int B, int H, int W,
                             int max_distance, unflow_stream_t stream);
 
+/* Fused backward of  ternary_loss(im1, image_warp(im2, flow), mask)  with respect to the FLOW
+ * (losses.py:22,82-83 -> core/image_warp.py): im2_warped = image_warp(im2, flow) and dldd come
+ * from the forward calls; d_flow [B,H,W,2] is overwritten.  The [B,H,W,3] gradient image of
+ * unflow_ternary_loss_bwd is never materialised.  max_distance 2 or 3, B*H*W < 2^29; otherwise
+ * UNFLOW_ERR_INVALID_ARGUMENT (compose unflow_ternary_loss_bwd + unflow_image_warp_bwd). */
+int unflow_ternary_loss_warp_bwd(const float *im1, const float *im2_warped, const float *dldd,
+                                 const float *gout, const float *im2, const float *flow,
+                                 float *d_flow, int B, int H, int W, int max_distance,
+                                 unflow_stream_t stream);
+
 /* ---------------------------------------------------------------- masks, charbonnier
  * create_outgoing_mask (losses.py:347-366): mask [B,H,W,1]. */
 int unflow_outgoing_mask(const float *flow, float *mask, int B, int H, int W, unflow_stream_t stream);

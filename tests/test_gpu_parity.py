@@ -582,6 +582,30 @@ def test_integer_census_bit_exact(oracle_mod, dev, B, H, W, r, eps):
         losses.census_transform(T(im1, dev), 4)
 
 
+@pytest.mark.parametrize("r", [1, 2, 3])
+def test_ternary_loss_warped_gradient(oracle_mod, dev, r):
+    """ternary_loss_warped == ternary_loss(image_warp(.)) in value and in d/d flow (fused backward for
+    r = 2, 3), and the flow gradient matches the oracle's census gradient pushed through its warp gradient."""
+    from unflow_amd import losses
+    from unflow_amd.image_warp import image_warp
+    rng = np.random.default_rng(60 + r)
+    B, H, W = 2, 70, 61
+    im1, im2, flow = _pair(rng, B, H, W)
+    mask = (rng.uniform(size=(B, H, W, 1)) > 0.1).astype(np.float32)
+    f1 = T(flow, dev).requires_grad_(True)
+    l1 = losses.ternary_loss_warped(T(im1, dev), T(im2, dev), f1, T(mask, dev), max_distance=r)
+    (l1 * 1.5).backward()
+    f2 = T(flow, dev).requires_grad_(True)
+    l2 = losses.ternary_loss(T(im1, dev), image_warp(T(im2, dev), f2), T(mask, dev), max_distance=r)
+    (l2 * 1.5).backward()
+    assert float(l1) == float(l2)
+    close(f1.grad, N(f2.grad), 1e-5, 1e-6 * float(f2.grad.abs().max()))
+    w = oracle_mod.image_warp(im2, flow)
+    g_im = oracle_mod.ternary_loss_grad(im1, w, mask, r, gout=1.5)
+    _, want = oracle_mod.image_warp_grad(g_im, im2, flow, want_im=False)
+    close(f1.grad, want, 1e-3, 1e-4 * np.abs(want).max())
+
+
 def test_fused_loss_glue_matches_composition(oracle_mod, dev):
     """fb_occlusion_warp == fb_occlusion(image_warp(...)) bitwise; sym_loss == the charbonnier
     composition; compute_losses without aux (fused path) == with aux (composed path) == oracle."""

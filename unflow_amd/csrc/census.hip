@@ -360,10 +360,16 @@ __global__ __launch_bounds__(64 * kPairWaves) void ternary_fwd_pair_kernel(
   if (threadIdx.x == 0) partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = s;
 }
 
-template <int R, int ROWS>
+// FUSE: im2 is image_warp(im2_src, flow) and only d loss / d flow is wanted: the gradient
+// of the warp (core/image_warp.py autodiff, as image_warp_bwd_kernel) is applied to each
+// pixel's d_im2 = 255 * luma * dgray while it is still in registers, so the [B,H,W,3]
+// gradient image is neither written nor read back and one launch disappears.
+template <int R, int ROWS, bool FUSE = false>
 __global__ __launch_bounds__(64 * kPairWaves) void ternary_bwd_pair_kernel(
     const float *__restrict__ im1, const float *__restrict__ im2, const float *__restrict__ dldd,
-    const float *__restrict__ gout, float *__restrict__ d_im2, int H, int W) {
+    const float *__restrict__ gout, float *__restrict__ d_im2, int H, int W,
+    const float *__restrict__ im2_src = nullptr, const float2 *__restrict__ flow = nullptr,
+    float2 *__restrict__ d_flow = nullptr) {
   using HP = HalfPlane<R, ROWS>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *g1 = lds, *g2 = lds + HP::LW * HP::LH;
@@ -426,10 +432,31 @@ __global__ __launch_bounds__(64 * kPairWaves) void ternary_bwd_pair_kernel(
     ring[R] = 0.f;
     if (it >= R && col_ok && y < H) {
       const float dgray = acc * go;
-      float *out = d_im2 + (item_px + (long long)y * W + x) * 3;
-      out[0] = 255.f * 0.2989f * dgray;
-      out[1] = 255.f * 0.5870f * dgray;
-      out[2] = 255.f * 0.1140f * dgray;
+      const float gv[3] = {255.f * 0.2989f * dgray, 255.f * 0.5870f * dgray, 255.f * 0.1140f * dgray};
+      const long long p = item_px + (long long)y * W + x;
+      if constexpr (FUSE) {
+        const ClampTaps t = clamp_taps(x, y, flow[p], H, W);
+        const float *base = im2_src + item_px * 3;
+        const float *pa = base + t.ia * 3, *pb = base + t.ib * 3, *pc = base + t.ic * 3, *pd = base + t.id * 3;
+        float la[3], lb[3], lc[3], ld[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { la[c] = pa[c]; lb[c] = pb[c]; lc[c] = pc[c]; ld[c] = pd[c]; }
+        float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          ga = fmaf(gv[c], la[c], ga);
+          gb = fmaf(gv[c], lb[c], gb);
+          gc = fmaf(gv[c], lc[c], gc);
+          gd = fmaf(gv[c], ld[c], gd);
+        }
+        d_flow[p] = make_float2((gc - ga) * (1.f - t.yw) + (gd - gb) * t.yw,
+                                (gb - ga) * (1.f - t.xw) + (gd - gc) * t.xw);
+      } else {
+        float *out = d_im2 + p * 3;
+        out[0] = gv[0];
+        out[1] = gv[1];
+        out[2] = gv[2];
+      }
     }
   }
 }
@@ -879,4 +906,26 @@ extern "C" int unflow_sym_loss_fwd(const float *mask, const float *density, floa
   if (int rc = launch_status("sym_loss")) return rc;
   const double norm = norm_count > 0 ? (double)norm_count : (double)n;
   return reduce_partials(workspace, (int)grid, 1.0 / norm, loss, s);
+}
+
+extern "C" int unflow_ternary_loss_warp_bwd(const float *im1, const float *im2_warped, const float *dldd,
+                                            const float *gout, const float *im2, const float *flow, float *d_flow,
+                                            int B, int H, int W, int max_distance, unflow_stream_t stream) {
+  if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "ternary_loss_warp_grad: negative dimension");
+  if (max_distance < 2 || max_distance > 3 || (long long)B * H * W * 4 >= (1LL << 31))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT,
+                "ternary_loss_warp_grad: fused for max_distance 2 and 3 and fewer than 2^29 pixels; "
+                "compose unflow_ternary_loss_bwd and unflow_image_warp_bwd otherwise");
+  if ((long long)B * H * W == 0) return UNFLOW_OK;
+  hipStream_t s = as_stream(stream);
+  const int r = max_distance;
+#define LAUNCH_PAIR_FUSED(R)                                                                                   \
+  hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, kPairRowsFwd, true>), pair_grid(r, kPairRowsFwd, B, H, W),     \
+                     dim3(64 * kPairWaves), (pair_smem<R, kPairRowsFwd>(2)), s, im1, im2_warped, dldd, gout,    \
+                     static_cast<float *>(nullptr), H, W, im2, reinterpret_cast<const float2 *>(flow),          \
+                     reinterpret_cast<float2 *>(d_flow))
+  if (r == 2) LAUNCH_PAIR_FUSED(2);
+  else LAUNCH_PAIR_FUSED(3);
+#undef LAUNCH_PAIR_FUSED
+  return launch_status("ternary_loss_warp_bwd");
 }

@@ -329,6 +329,51 @@ class _TernaryLoss(torch.autograd.Function):
         return None, d, None, None, None
 
 
+class _TernaryWarped(torch.autograd.Function):
+    """ternary_loss(im1, image_warp(im2, flow), mask) with the backward fused down to the flow."""
+
+    @staticmethod
+    def forward(ctx, im1, im2, flow, mask, max_distance, norm_count):
+        im1, im2, mask = _dev(im1, "im1"), _dev(im2, "im2"), _dev(mask, "mask")
+        flow_d = _dev(flow.detach(), "flow")
+        B, H, W, C = im1.shape
+        if C != 3 or im2.shape != im1.shape or tuple(mask.shape) != (B, H, W, 1):
+            raise ValueError("ternary_loss_warped expects [B,H,W,3] images and a [B,H,W,1] mask")
+        im2_warped = image_warp(im2, flow_d)
+        loss = torch.empty((), device=im1.device, dtype=torch.float32)
+        dldd = torch.empty((B, H, W), device=im1.device, dtype=torch.float32)
+        ws = _workspace(B * H * W, im1.device)
+        with torch.cuda.device(im1.device):
+            _lib.check(_lib.load().unflow_ternary_loss_fwd(
+                _ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss), _ptr(dldd), _ptr(None), _ptr(ws),
+                B, H, W, max_distance, norm_count, _stream()))
+        ctx.save_for_backward(im1, im2, flow_d, im2_warped, dldd)
+        ctx.max_distance = max_distance
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        im1, im2, flow, im2_warped, dldd = ctx.saved_tensors
+        B, H, W, _ = im1.shape
+        gout = gout.contiguous()
+        d_flow = torch.empty_like(flow)
+        with torch.cuda.device(im1.device):
+            _lib.check(_lib.load().unflow_ternary_loss_warp_bwd(
+                _ptr(im1), _ptr(im2_warped), _ptr(dldd), _ptr(gout), _ptr(im2), _ptr(flow), _ptr(d_flow),
+                B, H, W, ctx.max_distance, _stream()))
+        return None, None, d_flow, None, None, None
+
+
+def ternary_loss_warped(im1, im2, flow, mask, max_distance=1, norm_count=0):
+    """``ternary_loss(im1, image_warp(im2, flow), mask, max_distance)`` (losses.py:22,82-83) whose
+    backward goes straight to ``flow``: for max_distance 2 and 3 one kernel instead of the
+    census backward, a [B,H,W,3] gradient image and the warp backward.  Other radii compose
+    the two ops."""
+    if max_distance in (2, 3) and im1.numel() // 3 < (1 << 29):
+        return _TernaryWarped.apply(im1, im2, flow, mask, max_distance, norm_count)
+    return ternary_loss(im1, image_warp(im2, flow), mask, max_distance, norm_count)
+
+
 def ternary_loss(im1, im2_warped, mask, max_distance=1, norm_count=0):
     """Soft ternary census + "Hamming" distance + charbonnier (losses.py:90-122),
     one fused kernel.  Gradient flows into ``im2_warped`` only."""
@@ -405,7 +450,9 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
 
     want = (lambda k: True) if terms is None else (lambda k: k in terms)
     im2_warped = im1_warped = None
-    if want('ternary') or want('photo') or want('grad') or return_aux:
+    # the warped images as graph nodes, unless the census term is their only consumer: then
+    # ternary_loss_warped warps inside and differentiates straight down to the flow
+    if want('photo') or want('grad') or return_aux:
         im2_warped = image_warp(im2, flow_fw)
         im1_warped = image_warp(im1, flow_bw)
     # Intermediates are only produced when something asks for them (TF1 runs just the nodes a
@@ -463,7 +510,12 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     if want('fb'):
         losses['fb'] = (charbonnier_loss(flow_fw + flow_bw_warped, mask_fw, norm_count=npx * 2) +
                         charbonnier_loss(flow_bw + flow_fw_warped, mask_bw, norm_count=npx * 2))
-    if want('ternary'):
+    if want('ternary') and im2_warped is None:
+        losses['ternary'] = (ternary_loss_warped(im1, im2, flow_fw, mask_fw, max_distance=data_max_distance,
+                                                 norm_count=npx) +
+                             ternary_loss_warped(im2, im1, flow_bw, mask_bw, max_distance=data_max_distance,
+                                                 norm_count=npx))
+    elif want('ternary'):
         losses['ternary'] = (ternary_loss(im1, im2_warped, mask_fw, max_distance=data_max_distance,
                                           norm_count=npx) +
                              ternary_loss(im2, im1_warped, mask_bw, max_distance=data_max_distance,
