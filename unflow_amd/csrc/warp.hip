@@ -608,6 +608,107 @@ __global__ __launch_bounds__(kBlock) void downsample_kernel(const float *__restr
   }
 }
 
+// Image gradient of image_warp (the scatter-add TF derives from tf.gather), LDS-privatised.
+// One workgroup owns a 64x16 tile of pixels; the cells its 2x2 taps touch form a bounding
+// box that -- for a coherent flow -- is little larger than the tile.  The taps are added
+// into an LDS window of that box with a compare-and-swap float add (ds_add_f32 retires a
+// lane per ~3 cycles on gfx950, profiles/ubench_lds_atomic.txt; a CAS round is an order of
+// magnitude cheaper at the low same-address contention of a warp), and the window is
+// flushed with global atomics over CONTIGUOUS rows of ww*C floats -- instead of 4*C strided
+// global atomics per pixel.  Tiles whose box does not fit fall back to those.
+__device__ inline void lds_add_f32(float *addr, float v) {
+  unsigned *ua = reinterpret_cast<unsigned *>(addr);
+  unsigned old = *ua, assumed;
+  do {
+    assumed = old;
+    old = atomicCAS(ua, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+  } while (old != assumed);
+}
+
+template <int C>
+__global__ __launch_bounds__(kSplatThreads) void image_warp_bwd_im_tiled_kernel(const float *__restrict__ grad,
+                                                                                const float2 *__restrict__ flow,
+                                                                                float *__restrict__ d_im, int H,
+                                                                                int W) {
+  __shared__ float win[kWinCells];
+  __shared__ int box[4];
+  const int x0 = blockIdx.x * kSX, y0 = blockIdx.y * kSY;
+  const long long item = (long long)blockIdx.z * H * W;
+  const int sx = x0 + (threadIdx.x % kSX), sy = y0 + threadIdx.x / kSX;
+  const bool live = sx < W && sy < H;
+  int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
+  float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f, g[C];
+  if (live) {
+    const long long p = item + (long long)sy * W + sx;
+    const ClampTaps t = clamp_taps(sx, sy, flow[p], H, W);
+    tx0 = (int)(t.ia % W); ty0 = (int)(t.ia / W);     // clamped tap coordinates
+    tx1 = (int)(t.id % W); ty1 = (int)(t.id / W);
+    wa = (1.f - t.xw) * (1.f - t.yw); wb = (1.f - t.xw) * t.yw;
+    wc = t.xw * (1.f - t.yw); wd = t.xw * t.yw;
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = grad[p * C + c];
+  }
+  if (threadIdx.x < 4) box[threadIdx.x] = 0x7fffffff;
+  __syncthreads();
+  {
+    int b0 = live ? tx0 : 0x7fffffff, b1 = live ? ty0 : 0x7fffffff;
+    int b2 = live ? -tx1 : 0x7fffffff, b3 = live ? -ty1 : 0x7fffffff;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      b0 = min(b0, __shfl_xor(b0, off, 64));
+      b1 = min(b1, __shfl_xor(b1, off, 64));
+      b2 = min(b2, __shfl_xor(b2, off, 64));
+      b3 = min(b3, __shfl_xor(b3, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && b0 != 0x7fffffff) {
+      atomicMin(&box[0], b0);
+      atomicMin(&box[1], b1);
+      atomicMin(&box[2], b2);
+      atomicMin(&box[3], b3);
+    }
+  }
+  __syncthreads();
+  const int wx0 = box[0], wy0 = box[1];
+  const int ww = -box[2] - wx0 + 1, wh = -box[3] - wy0 + 1;
+  float *base = d_im + item * C;
+  if (wx0 == 0x7fffffff) return;                       // no live pixel (cannot happen for a launched tile)
+  if ((long long)ww * wh * C > kWinCells) {            // incoherent flow: the strided global atomics
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        unsafeAtomicAdd(base + ((long long)ty0 * W + tx0) * C + c, wa * g[c]);
+        unsafeAtomicAdd(base + ((long long)ty1 * W + tx0) * C + c, wb * g[c]);
+        unsafeAtomicAdd(base + ((long long)ty0 * W + tx1) * C + c, wc * g[c]);
+        unsafeAtomicAdd(base + ((long long)ty1 * W + tx1) * C + c, wd * g[c]);
+      }
+    }
+    return;
+  }
+  const int cells = ww * wh * C;
+  for (int i = threadIdx.x; i < cells; i += kSplatThreads) win[i] = 0.f;
+  __syncthreads();
+  if (live) {
+    float *a = win + ((ty0 - wy0) * ww + (tx0 - wx0)) * C, *b = win + ((ty1 - wy0) * ww + (tx0 - wx0)) * C;
+    float *c_ = win + ((ty0 - wy0) * ww + (tx1 - wx0)) * C, *d = win + ((ty1 - wy0) * ww + (tx1 - wx0)) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      lds_add_f32(a + c, wa * g[c]);
+      lds_add_f32(b + c, wb * g[c]);
+      lds_add_f32(c_ + c, wc * g[c]);
+      lds_add_f32(d + c, wd * g[c]);
+    }
+  }
+  __syncthreads();
+  const int rowf = ww * C;                             // one window row = rowf contiguous floats in d_im
+  for (int ly = threadIdx.x >> 6; ly < wh; ly += kSplatThreads / 64) {
+    float *drow = base + ((long long)(wy0 + ly) * W + wx0) * C;
+    for (int i = threadIdx.x & 63; i < rowf; i += 64) {
+      const float v = win[ly * rowf + i];
+      if (v != 0.f) unsafeAtomicAdd(drow + i, v);
+    }
+  }
+}
+
 inline unsigned grid_for(long long total) {
   // memory-bound: cap the grid and grid-stride the rest (256 CUs x 8 blocks)
   long long g = (total + kBlock - 1) / kBlock;
@@ -694,7 +795,15 @@ extern "C" int unflow_image_warp_bwd(const float *grad, const float *im, const f
     case 3: IW_BWD(3, IM_, FL_); break;      \
     default: IW_BWD(0, IM_, FL_);            \
   }
-  if (d_im && d_flow) { IW_BWD_C(true, true) }
+  if (d_im && C >= 1 && C <= 3 && B <= 65535) {
+    // image gradient through the LDS-privatised scatter; the flow gradient (if wanted) separately
+    const dim3 tg((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B);
+    const float2 *fl = reinterpret_cast<const float2 *>(flow);
+    if (C == 1) hipLaunchKernelGGL(image_warp_bwd_im_tiled_kernel<1>, tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
+    else if (C == 2) hipLaunchKernelGGL(image_warp_bwd_im_tiled_kernel<2>, tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
+    else hipLaunchKernelGGL(image_warp_bwd_im_tiled_kernel<3>, tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
+    if (d_flow) { IW_BWD_C(false, true) }
+  } else if (d_im && d_flow) { IW_BWD_C(true, true) }
   else if (d_im) { IW_BWD_C(true, false) }
   else { IW_BWD_C(false, true) }
 #undef IW_BWD_C
