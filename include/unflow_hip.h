@@ -148,12 +148,13 @@ int unflow_create_mask(float *mask, int B, int H, int W, int pad_top, int pad_bo
 int unflow_fb_occlusion(const float *flow, const float *flow_other_warped, float *flow_diff,
                         float *occ, float *mask_inout, int B, int H, int W, unflow_stream_t stream);
 /* The same with flow_other_warped = image_warp(flow_other, flow) (losses.py:38-39) computed on
- * the fly; flow_other_warped (optional output), occ and mask_inout may be NULL.
+ * the fly; flow_other_warped (optional output), occ and mask_out may be NULL.
+ * mask_out = mask_in * (1 - occ) (losses.py:53-55); mask_in may be the same buffer.
  * unwarped_magnitude != 0: the threshold uses |flow_other|^2 at the pixel itself instead of
  * |flow_other_warped|^2 -- the variant of occlusion() (losses.py:125-134). */
 int unflow_fb_occlusion_warp(const float *flow, const float *flow_other, float *flow_other_warped,
-                             float *occ, float *mask_inout, int B, int H, int W,
-                             int unwarped_magnitude, unflow_stream_t stream);
+                             float *occ, const float *mask_in, float *mask_out, int B, int H,
+                             int W, int unwarped_magnitude, unflow_stream_t stream);
 /* One direction of losses['sym'] (losses.py:27-29,57-61): charbonnier_loss((1 - mask) -
  * cast(density < thresh)), density = forward_warp of the other flow; mask, density
  * [B,H,W,1].  No gradient (both operands are thresholded maps).  norm_count 0 = B*H*W. */

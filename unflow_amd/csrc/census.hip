@@ -631,8 +631,8 @@ __global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__
                                                                 const float2 *__restrict__ flow_other,
                                                                 float2 *__restrict__ warped_out,
                                                                 float *__restrict__ occ,
-                                                                float *__restrict__ mask_inout, int H, int W,
-                                                                int unwarped_magnitude, long long n) {
+                                                                const float *mask_in, float *mask_out, int H,
+                                                                int W, int unwarped_magnitude, long long n) {
   for (long long v = blockIdx.x * 256LL + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
     const TiledPixel tp = tiled_pixel(v, H, W);   // n = tiled_total(B, H, W): 64x4 pixel tiles
     if (!tp.ok) continue;
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__
     const float o = fb_occluded(f, w, unwarped_magnitude ? flow_other[p] : w, du, dv);
     if (warped_out) warped_out[p] = w;
     if (occ) occ[p] = o;
-    if (mask_inout) mask_inout[p] = mask_inout[p] * (1.f - o);
+    if (mask_out) mask_out[p] = mask_in[p] * (1.f - o);     // mask_in may be mask_out (in place)
   }
 }
 
@@ -879,15 +879,16 @@ extern "C" int unflow_census_hamming(const unsigned long long *sig1, const unsig
 }
 
 extern "C" int unflow_fb_occlusion_warp(const float *flow, const float *flow_other, float *flow_other_warped,
-                                        float *occ, float *mask_inout, int B, int H, int W,
-                                        int unwarped_magnitude, unflow_stream_t stream) {
+                                        float *occ, const float *mask_in, float *mask_out, int B, int H,
+                                        int W, int unwarped_magnitude, unflow_stream_t stream) {
   const long long n = (long long)B * H * W;
   if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp: negative dimension");
   if (n == 0) return UNFLOW_OK;
+  if (mask_out && !mask_in) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp: mask_out needs mask_in");
   const long long vn = tiled_total(B, H, W);
   hipLaunchKernelGGL(fb_occlusion_warp_kernel, dim3(ew_grid(vn)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other),
-                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_inout, H, W, unwarped_magnitude, vn);
+                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_in, mask_out, H, W, unwarped_magnitude, vn);
   return launch_status("fb_occlusion_warp");
 }
 

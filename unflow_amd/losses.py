@@ -82,10 +82,12 @@ def fb_occlusion(flow, flow_other_warped, mask_inout=None):
     return diff, occ
 
 
-def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False, unwarped_magnitude=False):
+def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False, unwarped_magnitude=False,
+                      mask_in=None):
     """``fb_occlusion(flow, image_warp(flow_other, flow), mask_inout)`` in one pass: the warped
     flow is computed on the fly and only written when ``want_warped``.  Returns (warped or
-    None, occ); no gradient (the occlusion map is a thresholded quantity)."""
+    None, occ); no gradient (the occlusion map is a thresholded quantity).  With ``mask_in``
+    the product ``mask_in * (1 - occ)`` is written to ``mask_inout`` instead of in place."""
     flow = _dev(flow.detach(), "flow")
     other = _dev(flow_other.detach(), "flow_other")
     _check_flow(None, flow)
@@ -95,9 +97,10 @@ def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False, unwa
     warped = torch.empty_like(flow) if want_warped else None
     occ = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
     with torch.cuda.device(flow.device):
-        _lib.check(_lib.load().unflow_fb_occlusion_warp(_ptr(flow), _ptr(other), _ptr(warped), _ptr(occ),
-                                                        _ptr(mask_inout), B, H, W,
-                                                        int(bool(unwarped_magnitude)), _stream()))
+        _lib.check(_lib.load().unflow_fb_occlusion_warp(
+            _ptr(flow), _ptr(other), _ptr(warped), _ptr(occ),
+            _ptr(mask_in if mask_in is not None else mask_inout), _ptr(mask_inout), B, H, W,
+            int(bool(unwarped_magnitude)), _stream()))
     return warped, occ
 
 
@@ -467,9 +470,13 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
         disocc_fw = (dens_fw < DISOCC_THRESH).float()
         disocc_bw = (dens_bw < DISOCC_THRESH).float()
 
+    fused_fb = mask_occlusion == 'fb' and not (want('fb') or return_aux)
     if border_mask is None:
         mask_fw = create_outgoing_mask(flow_fw)
         mask_bw = create_outgoing_mask(flow_bw)
+    elif fused_fb:       # the occlusion kernel writes border_mask * (1 - occ) into fresh buffers: no copies
+        mask_fw = torch.empty_like(border_mask)
+        mask_bw = torch.empty_like(border_mask)
     else:
         mask_fw = border_mask.clone()
         mask_bw = border_mask.clone()
@@ -481,8 +488,9 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
         _, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
         _, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
     elif mask_occlusion == 'fb':
-        _, fb_occ_fw = fb_occlusion_warp(flow_fw, flow_bw, mask_fw)
-        _, fb_occ_bw = fb_occlusion_warp(flow_bw, flow_fw, mask_bw)
+        src = border_mask if border_mask is not None else None
+        _, fb_occ_fw = fb_occlusion_warp(flow_fw, flow_bw, mask_fw, mask_in=src)
+        _, fb_occ_bw = fb_occlusion_warp(flow_bw, flow_fw, mask_bw, mask_in=src)
     if mask_occlusion == 'disocc':
         mask_fw = mask_fw * (1 - disocc_bw)
         mask_bw = mask_bw * (1 - disocc_fw)
