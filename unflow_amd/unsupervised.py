@@ -15,6 +15,13 @@ LOSSES = ['occ', 'sym', 'fb', 'grad', 'ternary', 'photo', 'smooth_1st', 'smooth_
 FLOW_SCALE = 5.0  # core/flownet.py:11
 
 
+# per pyramid level, finest first: (layer weight, census patch distance)
+#   default pyramid H/4 .. H/64                       unsupervised.py:85-86
+#   full_res: two more levels in front, H .. H/64     unsupervised.py:88-89
+_LEVELS = ((12.7, 3), (4.35, 2), (3.9, 2), (3.4, 1), (1.1, 1))
+_LEVELS_FULL_RES = ((12.7, 3), (5.5, 3), (5.0, 3), (4.35, 2), (3.9, 2), (3.4, 1), (1.1, 1))   # [3, 3] + the five
+
+
 def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, norm_batch=0):
     """``combined_loss`` (before the regularisation loss) and ``combined_losses`` of
     unsupervised.py:83-145.
@@ -25,45 +32,34 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     params: the reference's ``[train]`` dict -- ``full_res``, ``pyramid_loss``,
     ``mask_occlusion``, ``border_mask`` and the ``<loss>_weight`` entries.
     norm_batch (extension): global batch size when the call sees a batch shard."""
-    layer_weights = [12.7, 4.35, 3.9, 3.4, 1.1]
-    layer_patch_distances = [3, 2, 2, 1, 1]
-    if params.get('full_res'):
-        layer_weights = [12.7, 5.5, 5.0, 4.35, 3.9, 3.4, 1.1]
-        layer_patch_distances = [3, 3] + layer_patch_distances
-        im1_s, im2_s, mask_s = im1_norm, im2_norm, border_mask
-        final_flow_scale = FLOW_SCALE * 4
-    else:
-        im1_s = downsample(im1_norm, 4)
-        im2_s = downsample(im2_norm, 4)
-        mask_s = downsample(border_mask, 4)
-        final_flow_scale = FLOW_SCALE
-
-    combined_losses = {loss: 0.0 for loss in LOSSES}
-    combined_loss = 0.0
-    if params.get('pyramid_loss'):
-        flow_enum = list(enumerate(zip(flows_fw, flows_bw)))
-    else:
-        flow_enum = [(0, (flows_fw[0], flows_bw[0]))]
     mask_occlusion = params.get('mask_occlusion', '')
-    assert mask_occlusion in ['fb', 'disocc', '']
+    if mask_occlusion not in ('fb', 'disocc', ''):
+        raise AssertionError("mask_occlusion must be 'fb', 'disocc' or ''")      # :124
+    if params.get('full_res'):
+        levels, top_scale = _LEVELS_FULL_RES, FLOW_SCALE * 4                   # :90-96
+        images = (im1_norm, im2_norm, border_mask)
+    else:
+        levels, top_scale = _LEVELS, FLOW_SCALE                                # :97-103
+        images = tuple(downsample(t, 4) for t in (im1_norm, im2_norm, border_mask))
+    n_levels = len(flows_fw) if params.get('pyramid_loss') else 1             # :110-113
     # TF1 only runs what the fetched scalar needs: terms without a weight are never evaluated
-    active = [loss for loss in LOSSES if params.get(loss + '_weight')]
+    weights = {name: params[name + '_weight'] for name in LOSSES if params.get(name + '_weight')}
 
-    for n, (i, (flow_fw_s, flow_bw_s)) in enumerate(flow_enum):
-        flow_scale = final_flow_scale / (2 ** i)
-        layer_weight = layer_weights[i]
-        losses = compute_losses(im1_s, im2_s, flow_fw_s * flow_scale, flow_bw_s * flow_scale,
-                                border_mask=mask_s if params.get('border_mask') else None,
-                                mask_occlusion=mask_occlusion,
-                                data_max_distance=layer_patch_distances[i],
-                                norm_batch=norm_batch, terms=active)
+    total = 0.0
+    per_term = {name: 0.0 for name in LOSSES}
+    for i in range(n_levels):
+        layer_weight, patch_distance = levels[i]
+        scale = top_scale / (2 ** i)                                           # :118
+        im1_s, im2_s, mask_s = images
+        level = compute_losses(im1_s, im2_s, flows_fw[i] * scale, flows_bw[i] * scale,
+                               border_mask=mask_s if params.get('border_mask') else None,
+                               mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
+                               norm_batch=norm_batch, terms=tuple(weights))
         layer_loss = 0.0
-        for loss in active:
-            layer_loss = layer_loss + params[loss + '_weight'] * losses[loss]
-            combined_losses[loss] = combined_losses[loss] + layer_weight * losses[loss]
-        combined_loss = combined_loss + layer_weight * layer_loss
-        if n + 1 < len(flow_enum):   # the reference also shrinks after the last level; the result is unused
-            im1_s = downsample(im1_s, 2)
-            im2_s = downsample(im2_s, 2)
-            mask_s = downsample(mask_s, 2)
-    return combined_loss, combined_losses
+        for name, weight in weights.items():                                   # :134-139
+            layer_loss = layer_loss + weight * level[name]
+            per_term[name] = per_term[name] + layer_weight * level[name]
+        total = total + layer_weight * layer_loss                              # :141
+        if i + 1 < n_levels:   # the reference also shrinks after the last level; that result is unused
+            images = tuple(downsample(t, 2) for t in images)                   # :143-145
+    return total, per_term
