@@ -125,12 +125,20 @@ int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped, const flo
                             const float *gout, float *d_im2_warped, int B, int H, int W,
                             int max_distance, unflow_stream_t stream);
 
-/* Fused backward of  ternary_loss(im1, image_warp(im2, flow), mask)  with respect to the FLOW
- * (losses.py:22,82-83 -> core/image_warp.py): im2_warped = image_warp(im2, flow) and dldd come
- * from the forward calls; d_flow [B,H,W,2] is overwritten.  The [B,H,W,3] gradient image of
- * unflow_ternary_loss_bwd is never materialised.  max_distance 2 or 3, B*H*W < 2^29; otherwise
- * UNFLOW_ERR_INVALID_ARGUMENT (compose unflow_ternary_loss_bwd + unflow_image_warp_bwd). */
-int unflow_ternary_loss_warp_bwd(const float *im1, const float *im2_warped, const float *dldd,
+/* ternary_loss(im1, image_warp(im2, flow), mask) as one forward and one backward kernel
+ * (losses.py:22,82-83 -> core/image_warp.py + losses.py:90-122), for max_distance 2 or 3 and
+ * B*H*W < 2^29 (otherwise UNFLOW_ERR_INVALID_ARGUMENT: compose the separate entry points).
+ * _fwd: im2 is the UNWARPED image; the warp is evaluated while the census tiles are staged,
+ *   the warped RGB image is never materialised.  Outputs: loss, dldd [B,H,W] and the two gray
+ *   planes gray1 = 255*gray(im1), gray2_warped = 255*gray(image_warp(im2, flow)) [B,H,W] that
+ *   the backward reads.  workspace / norm_count as unflow_ternary_loss_fwd.
+ * _bwd: d_flow [B,H,W,2] = d loss / d flow * gout; the [B,H,W,3] gradient image of
+ *   unflow_ternary_loss_bwd is not materialised either. */
+int unflow_ternary_loss_warp_fwd(const float *im1, const float *im2, const float *flow,
+                                 const float *mask, float *loss, float *dldd, float *gray1,
+                                 float *gray2_warped, float *workspace, int B, int H, int W,
+                                 int max_distance, long long norm_count, unflow_stream_t stream);
+int unflow_ternary_loss_warp_bwd(const float *gray1, const float *gray2_warped, const float *dldd,
                                  const float *gout, const float *im2, const float *flow,
                                  float *d_flow, int B, int H, int W, int max_distance,
                                  unflow_stream_t stream);

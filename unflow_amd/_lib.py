@@ -37,6 +37,7 @@ SIGNATURES = {
     "unflow_reduce_workspace_floats": (ctypes.c_size_t, [_LL]),
     "unflow_ternary_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),
     "unflow_ternary_loss_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_ternary_loss_warp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),
     "unflow_ternary_loss_warp_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "unflow_outgoing_mask": (_I, [_P, _P, _I, _I, _I, _P]),
     "unflow_create_mask": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P]),

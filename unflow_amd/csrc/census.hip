@@ -287,6 +287,65 @@ __device__ inline void stage_gray_pair(const float *__restrict__ im1, const floa
   }
 }
 
+// Staging for ternary_loss(im1, image_warp(im2, flow)): the warp (core/image_warp.py order of
+// operations, as image_warp_fwd_kernel<3>) is evaluated per tile cell and goes straight into
+// the gray LDS image; the warped RGB image never exists.  The two gray values of the block's
+// OWN pixels are also written out (2 x 4 B/pixel) for the backward pass.
+template <int R, int ROWS>
+__device__ inline void stage_gray_pair_warped(const float *__restrict__ im1, const float *__restrict__ im2,
+                                              const float2 *__restrict__ flow, float *g1, float *g2,
+                                              float *__restrict__ gray1_out, float *__restrict__ gray2_out,
+                                              long long item_px, int H, int W, int x0, int y0) {
+  using HP = HalfPlane<R, ROWS>;
+  const float *base = im2 + item_px * 3;
+  for (int i = threadIdx.x; i < HP::LW * HP::LH; i += 64 * kPairWaves) {
+    const int ly = i / HP::LW, lx = i - ly * HP::LW;
+    const int y = y0 + ly - R, x = x0 + lx - 2 * R;
+    float a = 0.f, b = 0.f;
+    if (y >= 0 && y < H && x >= 0 && x < W) {
+      const long long p = item_px + (long long)y * W + x;
+      a = gray255(im1 + p * 3);
+      const ClampTaps t = clamp_taps(x, y, flow[p], H, W);
+      const float *pa = base + t.ia * 3, *pb = base + t.ib * 3, *pc = base + t.ic * 3, *pd = base + t.id * 3;
+      float la[3], lb[3], lc[3], ld[3], wpx[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { la[c] = pa[c]; lb[c] = pb[c]; lc[c] = pc[c]; ld[c] = pd[c]; }
+      const float wa = (1.f - t.xw) * (1.f - t.yw), wb = (1.f - t.xw) * t.yw;
+      const float wc = t.xw * (1.f - t.yw), wd = t.xw * t.yw;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float v = mul_rn(wa, la[c]);
+        v = add_rn(v, mul_rn(wb, lb[c]));
+        v = add_rn(v, mul_rn(wc, lc[c]));
+        v = add_rn(v, mul_rn(wd, ld[c]));
+        wpx[c] = v;
+      }
+      b = gray255(wpx);
+      if (lx >= 2 * R && lx < 2 * R + HP::COLS && ly >= R && ly < R + kPairWaves * ROWS) {   // the block's own pixel
+        gray1_out[p] = a;
+        gray2_out[p] = b;
+      }
+    }
+    g1[i] = a;
+    g2[i] = b;
+  }
+}
+
+// Staging from the two gray planes the warped forward wrote (zero outside the image)
+template <int R, int ROWS>
+__device__ inline void stage_gray_planes(const float *__restrict__ gray1, const float *__restrict__ gray2, float *g1,
+                                         float *g2, long long item_px, int H, int W, int x0, int y0) {
+  using HP = HalfPlane<R, ROWS>;
+  for (int i = threadIdx.x; i < HP::LW * HP::LH; i += 64 * kPairWaves) {
+    const int ly = i / HP::LW, lx = i - ly * HP::LW;
+    const int y = y0 + ly - R, x = x0 + lx - 2 * R;
+    const bool in = y >= 0 && y < H && x >= 0 && x < W;
+    const long long p = item_px + (long long)y * W + x;
+    g1[i] = in ? gray1[p] : 0.f;
+    g2[i] = in ? gray2[p] : 0.f;
+  }
+}
+
 template <int K, int N, class F>
 __device__ inline void static_for_pairs(F &&f) {
   if constexpr (K < N) {
@@ -295,17 +354,21 @@ __device__ inline void static_for_pairs(F &&f) {
   }
 }
 
-template <int R, int ROWS>
+// WARP: im2 is the UNWARPED image and flow is given: im2_warped = image_warp(im2, flow) is
+// evaluated while staging (see stage_gray_pair_warped) and the gray planes are written out.
+template <int R, int ROWS, bool WARP = false>
 __global__ __launch_bounds__(64 * kPairWaves) void ternary_fwd_pair_kernel(
     const float *__restrict__ im1, const float *__restrict__ im2, const float *__restrict__ mask,
     float *__restrict__ partial, float *__restrict__ dldd, float *__restrict__ dist_out, int H, int W,
-    float inv_norm) {
+    float inv_norm, const float2 *__restrict__ flow = nullptr, float *__restrict__ gray1_out = nullptr,
+    float *__restrict__ gray2_out = nullptr) {
   using HP = HalfPlane<R, ROWS>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *g1 = lds, *g2 = lds + HP::LW * HP::LH;
   const int x0 = blockIdx.x * HP::COLS, y0 = blockIdx.y * (kPairWaves * ROWS);
   const long long item_px = (long long)blockIdx.z * H * W;
-  stage_gray_pair<R, ROWS>(im1, im2, g1, g2, item_px, H, W, x0, y0);
+  if constexpr (WARP) stage_gray_pair_warped<R, ROWS>(im1, im2, flow, g1, g2, gray1_out, gray2_out, item_px, H, W, x0, y0);
+  else stage_gray_pair<R, ROWS>(im1, im2, g1, g2, item_px, H, W, x0, y0);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -375,7 +438,9 @@ __global__ __launch_bounds__(64 * kPairWaves) void ternary_bwd_pair_kernel(
   float *g1 = lds, *g2 = lds + HP::LW * HP::LH;
   const int x0 = blockIdx.x * HP::COLS, y0 = blockIdx.y * (kPairWaves * ROWS);
   const long long item_px = (long long)blockIdx.z * H * W;
-  stage_gray_pair<R, ROWS>(im1, im2, g1, g2, item_px, H, W, x0, y0);
+  // FUSE: im1 / im2 are the two GRAY planes written by the warped forward
+  if constexpr (FUSE) stage_gray_planes<R, ROWS>(im1, im2, g1, g2, item_px, H, W, x0, y0);
+  else stage_gray_pair<R, ROWS>(im1, im2, g1, g2, item_px, H, W, x0, y0);
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -909,7 +974,37 @@ extern "C" int unflow_sym_loss_fwd(const float *mask, const float *density, floa
   return reduce_partials(workspace, (int)grid, 1.0 / norm, loss, s);
 }
 
-extern "C" int unflow_ternary_loss_warp_bwd(const float *im1, const float *im2_warped, const float *dldd,
+extern "C" int unflow_ternary_loss_warp_fwd(const float *im1, const float *im2, const float *flow, const float *mask,
+                                            float *loss, float *dldd, float *gray1, float *gray2_warped,
+                                            float *workspace, int B, int H, int W, int max_distance,
+                                            long long norm_count, unflow_stream_t stream) {
+  if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "ternary_loss_warp: negative dimension");
+  if (max_distance < 2 || max_distance > 3 || (long long)B * H * W * 4 >= (1LL << 31))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT,
+                "ternary_loss_warp: fused for max_distance 2 and 3 and fewer than 2^29 pixels; "
+                "compose unflow_image_warp_fwd and unflow_ternary_loss_fwd otherwise");
+  hipStream_t s = as_stream(stream);
+  const long long npix = (long long)B * H * W;
+  if (npix == 0) {
+    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("ternary_loss_warp memset");
+    return UNFLOW_OK;
+  }
+  const double norm = norm_count > 0 ? (double)norm_count : (double)npix;
+  const int r = max_distance;
+  const dim3 pgrid = pair_grid(r, kPairRowsFwd, B, H, W);
+#define LAUNCH_PAIR_WARP(R)                                                                                    \
+  hipLaunchKernelGGL((ternary_fwd_pair_kernel<R, kPairRowsFwd, true>), pgrid, dim3(64 * kPairWaves),            \
+                     (pair_smem<R, kPairRowsFwd>(2)), s, im1, im2, mask, workspace, dldd,                       \
+                     static_cast<float *>(nullptr), H, W, (float)(1.0 / norm),                                  \
+                     reinterpret_cast<const float2 *>(flow), gray1, gray2_warped)
+  if (r == 2) LAUNCH_PAIR_WARP(2);
+  else LAUNCH_PAIR_WARP(3);
+#undef LAUNCH_PAIR_WARP
+  if (int rc = launch_status("ternary_loss_warp_fwd")) return rc;
+  return reduce_partials(workspace, (int)(pgrid.x * pgrid.y * pgrid.z), 1.0 / norm, loss, s);
+}
+
+extern "C" int unflow_ternary_loss_warp_bwd(const float *gray1, const float *gray2_warped, const float *dldd,
                                             const float *gout, const float *im2, const float *flow, float *d_flow,
                                             int B, int H, int W, int max_distance, unflow_stream_t stream) {
   if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "ternary_loss_warp_grad: negative dimension");
@@ -922,7 +1017,7 @@ extern "C" int unflow_ternary_loss_warp_bwd(const float *im1, const float *im2_w
   const int r = max_distance;
 #define LAUNCH_PAIR_FUSED(R)                                                                                   \
   hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, kPairRowsFwd, true>), pair_grid(r, kPairRowsFwd, B, H, W),     \
-                     dim3(64 * kPairWaves), (pair_smem<R, kPairRowsFwd>(2)), s, im1, im2_warped, dldd, gout,    \
+                     dim3(64 * kPairWaves), (pair_smem<R, kPairRowsFwd>(2)), s, gray1, gray2_warped, dldd, gout, \
                      static_cast<float *>(nullptr), H, W, im2, reinterpret_cast<const float2 *>(flow),          \
                      reinterpret_cast<float2 *>(d_flow))
   if (r == 2) LAUNCH_PAIR_FUSED(2);

@@ -333,45 +333,46 @@ class _TernaryLoss(torch.autograd.Function):
 
 
 class _TernaryWarped(torch.autograd.Function):
-    """ternary_loss(im1, image_warp(im2, flow), mask) with the backward fused down to the flow."""
+    """ternary_loss(im1, image_warp(im2, flow), mask): warp fused into the census forward,
+    backward fused down to the flow; neither the warped image nor its gradient exists."""
 
     @staticmethod
     def forward(ctx, im1, im2, flow, mask, max_distance, norm_count):
         im1, im2, mask = _dev(im1, "im1"), _dev(im2, "im2"), _dev(mask, "mask")
         flow_d = _dev(flow.detach(), "flow")
+        _check_flow(im1, flow_d)
         B, H, W, C = im1.shape
         if C != 3 or im2.shape != im1.shape or tuple(mask.shape) != (B, H, W, 1):
             raise ValueError("ternary_loss_warped expects [B,H,W,3] images and a [B,H,W,1] mask")
-        im2_warped = image_warp(im2, flow_d)
         loss = torch.empty((), device=im1.device, dtype=torch.float32)
-        dldd = torch.empty((B, H, W), device=im1.device, dtype=torch.float32)
+        dldd, gray1, gray2w = (torch.empty((B, H, W), device=im1.device, dtype=torch.float32) for _ in range(3))
         ws = _workspace(B * H * W, im1.device)
         with torch.cuda.device(im1.device):
-            _lib.check(_lib.load().unflow_ternary_loss_fwd(
-                _ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss), _ptr(dldd), _ptr(None), _ptr(ws),
-                B, H, W, max_distance, norm_count, _stream()))
-        ctx.save_for_backward(im1, im2, flow_d, im2_warped, dldd)
+            _lib.check(_lib.load().unflow_ternary_loss_warp_fwd(
+                _ptr(im1), _ptr(im2), _ptr(flow_d), _ptr(mask), _ptr(loss), _ptr(dldd), _ptr(gray1), _ptr(gray2w),
+                _ptr(ws), B, H, W, max_distance, norm_count, _stream()))
+        ctx.save_for_backward(im2, flow_d, gray1, gray2w, dldd)
         ctx.max_distance = max_distance
         return loss
 
     @staticmethod
     def backward(ctx, gout):
-        im1, im2, flow, im2_warped, dldd = ctx.saved_tensors
-        B, H, W, _ = im1.shape
+        im2, flow, gray1, gray2w, dldd = ctx.saved_tensors
+        B, H, W, _ = im2.shape
         gout = gout.contiguous()
         d_flow = torch.empty_like(flow)
-        with torch.cuda.device(im1.device):
+        with torch.cuda.device(im2.device):
             _lib.check(_lib.load().unflow_ternary_loss_warp_bwd(
-                _ptr(im1), _ptr(im2_warped), _ptr(dldd), _ptr(gout), _ptr(im2), _ptr(flow), _ptr(d_flow),
+                _ptr(gray1), _ptr(gray2w), _ptr(dldd), _ptr(gout), _ptr(im2), _ptr(flow), _ptr(d_flow),
                 B, H, W, ctx.max_distance, _stream()))
         return None, None, d_flow, None, None, None
 
 
 def ternary_loss_warped(im1, im2, flow, mask, max_distance=1, norm_count=0):
     """``ternary_loss(im1, image_warp(im2, flow), mask, max_distance)`` (losses.py:22,82-83) whose
-    backward goes straight to ``flow``: for max_distance 2 and 3 one kernel instead of the
-    census backward, a [B,H,W,3] gradient image and the warp backward.  Other radii compose
-    the two ops."""
+    forward evaluates the warp while staging the census tiles and whose backward goes straight
+    to ``flow`` (max_distance 2 and 3): two kernels instead of four, and neither the warped
+    image nor its [B,H,W,3] gradient touches HBM.  Other radii compose the two ops."""
     if max_distance in (2, 3) and im1.numel() // 3 < (1 << 29):
         return _TernaryWarped.apply(im1, im2, flow, mask, max_distance, norm_count)
     return ternary_loss(im1, image_warp(im2, flow), mask, max_distance, norm_count)
