@@ -7,11 +7,12 @@ One "step" = one pass of the whole path over a batch of image pairs
   * FlowNetC correlation, both directions (core/flownet.py:35-43 runs it fw and
     bw): 2 forward calls on [B,256,H/8,W/8] and their 2 backward calls;
   * one level-0 ``compute_losses`` at full resolution, max_distance=3
-    (core/unsupervised.py:87-95): the 4 image_warp (2 of the images; the 2 of the
-    flows are evaluated inside the fb-occlusion mask kernel, nothing else reads
-    them), fb-occlusion masks, 2 forward_warp disocclusion densities + the 'sym'
-    term, 2 soft-census ternary losses 7x7 with the charbonnier reductions --
-    forward, then backward to dL/dflow_fw, dL/dflow_bw;
+    (core/unsupervised.py:87-95): the 4 image_warp (the 2 of the images are
+    evaluated inside the census kernels, the 2 of the flows inside the
+    fb-occlusion mask kernel: nothing else reads them), fb-occlusion masks, 2
+    forward_warp disocclusion densities + the 'sym' term, 2 soft-census ternary
+    losses 7x7 with the charbonnier reductions -- forward, then backward to
+    dL/dflow_fw, dL/dflow_bw;
   * with N>1 ranks: RCCL all-reduce of the loss scalar and of a 156.7 MB
     gradient buffer standing in for the FlowNetC weights.
 
@@ -219,8 +220,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "cfg3: 384x1280 pairs, batch %d per GPU: 2x FlowNetC correlation fwd+bwd on "
-                                   "[B,256,48,160] + level-0 compute_losses (2 image_warp of the images, fb-occlusion masks with the "
-                                   "2 flow warps computed on the fly, 2 forward_warp + sym term, 2 ternary 7x7) fwd+bwd" % args.batch,
+                                   "[B,256,48,160] + level-0 compute_losses (4 image_warp evaluated inside the census and fb-occlusion "
+                                   "kernels, 2 forward_warp + sym term, 2 ternary 7x7) fwd+bwd" % args.batch,
                        "global_batch": args.batch * world, "height": H, "width": W,
                        "parallelism": "batch-sharded x%d, all-reduce of loss + 156.7 MB grad buffer" % world},
             "roofline": {"bound": "mfma",
