@@ -111,11 +111,15 @@ class Workload:
         return loss.detach(), (c_fw, c_bw, g_fw, g_bw)
 
 
-def cpu_baseline(n_pairs=2):
+def cpu_baseline(n_pairs=2, threads=0):
     """The CPU oracle (a restatement: kind "port") timed on this host over a bounded
-    sample of the same step: n_pairs 384x1280 pairs, all host threads."""
+    sample of the same step: n_pairs 384x1280 pairs, all host threads (threads=0) or
+    the given number."""
     import oracle
     oracle.build()
+    all_threads = oracle.num_threads()
+    if threads:
+        oracle.set_num_threads(threads)
     rng = np.random.default_rng(1234)
     f0 = rng.standard_normal((n_pairs, FEAT_C, H8, W8)).astype(np.float32)
     f1 = rng.standard_normal((n_pairs, FEAT_C, H8, W8)).astype(np.float32)
@@ -135,7 +139,9 @@ def cpu_baseline(n_pairs=2):
     g1 = oracle.ternary_loss_grad(im2, aux["im1_warped"], aux["mask_bw"], 3)
     oracle.image_warp_grad(g1, im1, fbw, want_im=False)
     dt = time.perf_counter() - t0
-    return {"value": n_pairs / dt, "unit": "image-pairs/s", "cores": oracle.num_threads(), "kind": "port",
+    cores = oracle.num_threads()
+    oracle.set_num_threads(all_threads)
+    return {"value": n_pairs / dt, "unit": "image-pairs/s", "cores": cores, "kind": "port",
             "sample": "%d pairs of 384x1280 (same step: 2 corr fwd+bwd, level-0 loss fwd+bwd), %.1f s, "
                       "OpenMP C restatement oracle/unflow_oracle.c" % (n_pairs, dt)}
 
@@ -147,6 +153,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-single-thread", action="store_true",
+                    help="also time the CPU oracle on ONE thread (one pair, about a minute; SURVEY 8d)")
     ap.add_argument("--breakdown", action="store_true", help="also print per-op timings to stderr")
     args = ap.parse_args()
 
@@ -239,6 +247,8 @@ def main():
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if args.cpu_single_thread:
+                out["cpu_baseline"]["single_thread"] = cpu_baseline(n_pairs=1, threads=1)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
