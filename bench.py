@@ -274,6 +274,15 @@ def breakdown(wl, fwd_ms, bwd_ms):
     im2w = image_warp(wl.im2, ffw)
     g3 = torch.randn_like(im2w)
     rows = [("corr_fwd", fwd_ms, CORR_FWD_BYTES * B), ("corr_bwd", bwd_ms, CORR_BWD_BYTES * B)]
+    # extension: both directions of a bidirectional FlowNetC from one correlation (bit-exact re-indexing)
+    rows.append(("corr_fwd x2 via correlation_bidirectional (extension)",
+                 timeit(lambda: ops.correlation_bidirectional(wl.fa, wl.fb)), 2 * CORR_FWD_BYTES * B))
+    fa_g, fb_g = wl.fa.clone().requires_grad_(True), wl.fb.clone().requires_grad_(True)
+    cfw, cbw = ops.correlation_bidirectional(fa_g, fb_g)
+    rows.append(("corr_bwd x2 via correlation_bidirectional (extension)",
+                 timeit(lambda: torch.autograd.grad([cfw, cbw], [fa_g, fb_g], [wl.top_fw, wl.top_bw], retain_graph=True)),
+                 2 * CORR_BWD_BYTES * B))
+    del cfw, cbw, fa_g, fb_g
     fah, fbh = wl.fa.half(), wl.fb.half()
     rows.append(("corr_fwd, fp16 storage / f32 accumulate (extension)", timeit(lambda: ops.correlation_fp16(fah, fbh)),
                  CORR_FWD_BYTES * B // 2))

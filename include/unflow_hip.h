@@ -211,6 +211,19 @@ int unflow_gradient_loss_bwd(const float *im1, const float *im2_warped, const fl
 int unflow_gradient_delta(const float *im1, const float *im2_warped, float *diff, int B, int H, int W,
                           unflow_stream_t stream);
 
+/* ---------------------------------------------------------------- both directions (extension)
+ * A bidirectional FlowNetC runs correlation(a, b) and correlation(b, a) on the same pair
+ * (core/flownet.py:33-43).  The second volume is a re-indexing of the first,
+ *   corr(b, a)[d, p] = corr(a, b)[-d, p + stride_2 * d]   (0 where that leaves the image),
+ * bit-identical because the same products are summed in the same order.
+ * out = (add ? add : 0) + flip(in); in, add, out [B,D,H,W].  The map is its own inverse, so
+ * top_fw + flip(top_bw) is the upstream gradient of the first volume that makes ONE
+ * unflow_correlation_bwd call return the summed gradients of both directions.
+ * Needs kernel_size 1, stride_1 1, pad == max_displacement. */
+int unflow_correlation_flip(const float *in, const float *add, float *out, int B, int H, int W,
+                            int kernel_size, int max_displacement, int pad, int stride_1,
+                            int stride_2, unflow_stream_t stream);
+
 /* ---------------------------------------------------------------- fp16 storage (extension)
  * NOT in the reference (float32 only; BASELINE config 5 names "fp16 with fp32 accumulate").
  * Correlation with half-precision tensors in HBM: in0, in1 [B,C,H,W] and out

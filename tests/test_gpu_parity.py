@@ -249,6 +249,31 @@ def test_correlation_fp16_storage(oracle_mod, dev, shape):
         ops.correlation_fp16(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1).to(dev))
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 16, 24), (1, 7, 9, 13), (2, 16, 48, 160)])
+def test_correlation_bidirectional(oracle_mod, dev, shape):
+    """Extension for the bidirectional FlowNetC (core/flownet.py:33-43): the cost volume of (b, a) is a
+    bit-exact re-indexing of that of (a, b), and one backward call yields the summed gradients."""
+    from unflow_amd import ops
+    rng = np.random.default_rng(sum(shape) + 1)
+    f0 = rng.standard_normal(shape).astype(np.float32)
+    f1 = rng.standard_normal(shape).astype(np.float32)
+    a, b = T(f0, dev).requires_grad_(True), T(f1, dev).requires_grad_(True)
+    c_fw, c_bw = ops.correlation_bidirectional(a, b)
+    assert torch.equal(c_fw, ops.correlation(a.detach(), b.detach()))
+    assert torch.equal(c_bw, ops.correlation(b.detach(), a.detach()))          # bit-identical
+    assert torch.equal(ops.correlation_flip(c_bw.detach()), c_fw.detach())       # the map is its own inverse
+    want_bw, _, _ = oracle_mod.correlation(f1, f0)
+    close(c_bw, want_bw)
+    t_fw = T(rng.standard_normal(c_fw.shape).astype(np.float32), dev)
+    t_bw = T(rng.standard_normal(c_fw.shape).astype(np.float32), dev)
+    ((c_fw * t_fw).sum() + (c_bw * t_bw).sum()).backward()
+    g0a, g1a = ops.correlation_grad(t_fw, a.detach(), b.detach())                # direction (a, b)
+    g0b, g1b = ops.correlation_grad(t_bw, b.detach(), a.detach())                # direction (b, a)
+    wa, wb = N(g0a + g1b), N(g1a + g0b)
+    close(a.grad, wa, 1e-5, 1e-5 * np.abs(wa).max())
+    close(b.grad, wb, 1e-5, 1e-5 * np.abs(wb).max())
+
+
 def test_correlation_errors(dev):
     from unflow_amd import ops
     f = torch.zeros((1, 1, 4, 4), device=dev)

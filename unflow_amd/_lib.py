@@ -52,6 +52,7 @@ SIGNATURES = {
     "unflow_gradient_loss_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _LL, _P]),
     "unflow_gradient_loss_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _LL, _P]),
     "unflow_gradient_delta": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "unflow_correlation_flip": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_fwd_f16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_bwd_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_census_transform": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),

@@ -274,3 +274,56 @@ extern "C" int unflow_correlation_bwd(const float *topdiff, const float *in0, co
                      C, total);
   return launch_status("correlation_bwd");
 }
+
+// ---------------------------------------------------------------------------
+// Both directions of a bidirectional FlowNetC (core/flownet.py:33-43 runs
+// correlation(a, b) and correlation(b, a) on the same feature pair).  The second cost
+// volume is a re-indexing of the first:
+//   corr(b, a)[d, p] = 1/C sum_c b[c, p] a[c, p + s2*d] = corr(a, b)[-d, p + s2*d]
+// (0 where p + s2*d leaves the image: the zero padding), the very same products summed
+// in the very same order, hence bit-identical.  This kernel applies that map, which
+// is its own inverse; with `add` it computes add + flip(in), which folds the upstream
+// gradient of the second volume into that of the first so that ONE backward call
+// yields the summed gradients.
+// ---------------------------------------------------------------------------
+namespace unflow {
+namespace {
+__global__ __launch_bounds__(256) void corr_flip_kernel(const float *__restrict__ in, const float *__restrict__ add,
+                                                        float *__restrict__ out, int gw, int s2, int H, int W,
+                                                        long long total) {
+  const int r = gw / 2, D = gw * gw;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    long long t = i / W;
+    const int y = (int)(t % H);
+    t /= H;
+    const int d = (int)(t % D);
+    const long long b = t / D;
+    const int dy = d / gw - r, dx = d % gw - r;
+    const int yy = y + s2 * dy, xx = x + s2 * dx;
+    float v = add ? add[i] : 0.f;
+    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+      const float f = in[((b * D + (D - 1 - d)) * H + yy) * W + xx];
+      v = add ? v + f : f;
+    }
+    out[i] = v;
+  }
+}
+}  // namespace
+}  // namespace unflow
+
+extern "C" int unflow_correlation_flip(const float *in, const float *add, float *out, int B, int H, int W,
+                                       int kernel_size, int max_displacement, int pad, int stride_1, int stride_2,
+                                       unflow_stream_t stream) {
+  CorrGeometry g;
+  if (int rc = corr_geometry_init(&g, H, W, kernel_size, max_displacement, pad, stride_1, stride_2)) return rc;
+  if (kernel_size != 1 || stride_1 != 1 || pad != max_displacement || g.out_height != H || g.out_width != W)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT,
+                "correlation_flip needs kernel_size 1, stride_1 1 and pad == max_displacement (output grid == input grid)");
+  if (B < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation_flip: negative dimension");
+  const long long total = (long long)B * g.out_channels * H * W;
+  if (total == 0) return UNFLOW_OK;
+  hipLaunchKernelGGL(corr_flip_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), in, add, out,
+                     g.grid_width, stride_2, H, W, total);
+  return launch_status("correlation_flip");
+}

@@ -218,6 +218,51 @@ def correlation(first, second, kernel_size=1, max_displacement=20, pad=20, strid
     return _Correlation.apply(first, second, kernel_size, max_displacement, pad, stride_1, stride_2)
 
 
+def correlation_flip(volume, add=None, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
+    """``add + flip(volume)``: flip maps the cost volume of (a, b) onto that of (b, a),
+    ``flip(c)[d, p] = c[-d, p + stride_2*d]`` (0 outside the image); it is its own inverse."""
+    volume = _dev(volume, "volume")
+    _require_rank4(volume, "volume")
+    if add is not None:
+        add = _dev(add, "add")
+        if add.shape != volume.shape:
+            raise ValueError("add must have the shape of volume")
+    B, D, H, W = volume.shape
+    out = torch.empty_like(volume)
+    with torch.cuda.device(volume.device):
+        _lib.check(_lib.load().unflow_correlation_flip(_ptr(volume), _ptr(add), _ptr(out), B, H, W, kernel_size,
+                                                       max_displacement, pad, stride_1, stride_2, _stream()))
+    return out
+
+
+class _CorrelationBidirectional(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, first, second, attrs):
+        c_fw, _, _ = _correlation_raw(first, second, False, *attrs)
+        c_bw = correlation_flip(c_fw, None, *attrs)
+        ctx.save_for_backward(first, second)
+        ctx.attrs = attrs
+        return c_fw, c_bw
+
+    @staticmethod
+    def backward(ctx, g_fw, g_bw):
+        first, second = ctx.saved_tensors
+        top = correlation_flip(g_bw.contiguous(), g_fw.contiguous(), *ctx.attrs)      # g_fw + flip(g_bw)
+        k, md, pad, s1, s2 = ctx.attrs
+        g0, g1 = correlation_grad(top, first, second, None, None, kernel_size=k, max_displacement=md, pad=pad,
+                                  stride_1=s1, stride_2=s2)
+        return g0, g1, None
+
+
+def correlation_bidirectional(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
+    """Extension for the bidirectional FlowNetC (core/flownet.py:33-43 calls ``correlation(a, b)``
+    and ``correlation(b, a)``): returns both cost volumes from ONE correlation -- the second is
+    a bit-exact re-indexing of the first -- and its backward folds both upstream gradients into
+    one ``correlation_grad`` call that returns the summed gradients.  Needs kernel_size 1,
+    stride_1 1, pad == max_displacement."""
+    return _CorrelationBidirectional.apply(first, second, (kernel_size, max_displacement, pad, stride_1, stride_2))
+
+
 def _half(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float16:
         raise TypeError("%s must be a float16 CUDA/HIP tensor" % name)
