@@ -91,12 +91,20 @@ class Workload:
         self.corr_events.append((s, e, kind))
         return r
 
-    def step(self, world):
+    def step(self, world, bidirectional=False):
         with torch.no_grad():
-            c_fw = self._timed("corr_fwd", ops.correlation, self.fa, self.fb)
-            c_bw = self._timed("corr_fwd", ops.correlation, self.fb, self.fa)
-            g_fw = self._timed("corr_bwd", ops.correlation_grad, self.top_fw, self.fa, self.fb)
-            g_bw = self._timed("corr_bwd", ops.correlation_grad, self.top_bw, self.fb, self.fa)
+            if bidirectional:
+                # extension: corr(b, a) is a bit-exact re-indexing of corr(a, b), and one
+                # backward call on top_fw + flip(top_bw) returns the summed gradients
+                c_fw = ops.correlation(self.fa, self.fb)
+                c_bw = ops.correlation_flip(c_fw)
+                g_fw = ops.correlation_grad(ops.correlation_flip(self.top_bw, self.top_fw), self.fa, self.fb)
+                g_bw = None
+            else:
+                c_fw = self._timed("corr_fwd", ops.correlation, self.fa, self.fb)
+                c_bw = self._timed("corr_fwd", ops.correlation, self.fb, self.fa)
+                g_fw = self._timed("corr_bwd", ops.correlation_grad, self.top_fw, self.fa, self.fb)
+                g_bw = self._timed("corr_bwd", ops.correlation_grad, self.top_bw, self.fb, self.fa)
         self.flow_fw.grad = None
         self.flow_bw.grad = None
         ls = losses.compute_losses(self.im1, self.im2, self.flow_fw, self.flow_bw,
@@ -190,6 +198,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # for information only (never `value`): the same step with the bidirectional-correlation extension
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step(world, bidirectional=True)
+    fence()
+    dt_bidir = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dt_bidir], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_bidir = float(t.item())
+
     # dominant kernel: correlation backward (3.47 GFLOP/pair, f32 MFMA); averaged over the timed region
     per_kind = {}
     for s, e, kind in wl.corr_events:
@@ -245,6 +265,11 @@ def main():
                                       "hbm_gbs": CORR_FWD_BYTES * args.batch / (fwd_ms * 1e-3) / 1e9}},
             "loss": float(loss),
         }
+        out["extension_bidirectional_correlation"] = {
+            "note": "NOT the headline: the same step when the caller obtains the (b,a) cost volume as a bit-exact "
+                    "re-indexing of the (a,b) one and runs one backward call for both directions "
+                    "(ops.correlation_bidirectional, DESIGN.md 4.1)",
+            "ms_per_step": dt_bidir / args.steps * 1e3, "value": pairs / dt_bidir, "unit": "image-pairs/s"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if args.cpu_single_thread:
