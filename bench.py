@@ -19,21 +19,24 @@ One "step" = one pass of the whole path over a batch of image pairs
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+``--gpus N`` with N > 1 and no launcher environment (WORLD_SIZE unset) makes this
+process a pure launcher: it starts N fresh child processes (one rank per GPU, the
+reference splits its batch the same way, src/run.py:48) BEFORE it touches the GPU
+itself, waits for them and exits with their status.  Under ``torch.distributed.run``
+the ranks come from the environment.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from unflow_amd import losses, ops  # noqa: E402
 
 H, W, FEAT_C = 384, 1280, 256
 GRAD_BUFFER_FLOATS = 39_170_000  # FlowNetC weights, core/flownet.py:179-233 (SURVEY 8e): 156.7 MB
@@ -46,9 +49,72 @@ CORR_BWD_BYTES = 4 * H8 * W8 * (D + 4 * FEAT_C)          # 45.0 MB
 CORR_BWD_FLOP = 2 * CORR_FWD_FLOP                        # 3.47 GFLOP
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak
+KITTI = dict(pyramid_loss=True, border_mask=True, mask_occlusion="fb", ternary_weight=1.0,
+             smooth_2nd_weight=3.0, fb_weight=0.2, occ_weight=12.4)   # config_template/config.ini:79,98,123,166-174
 
 
-def smooth_images(gen, B):
+# ============================================================================= launcher
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-runs", type=int, default=5, help="timed repetitions of the CPU baseline (median)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the informational fields (warps roofline, kitti_config_step, extensions)")
+    ap.add_argument("--breakdown", action="store_true", help="also print per-op timings to stderr")
+    ap.add_argument("--backend", default=None, choices=("nccl", "gloo"),
+                    help="process-group backend (default: nccl = RCCL)")
+    ap.add_argument("--dry", action="store_true",
+                    help="launch and rendezvous only: no GPU work (CPU rehearsal of the N-rank launch path)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """Start args.gpus children, one rank each, and return the worst exit status.  The
+    parent never initialises the GPU (no HIP call, no torch.cuda query that would) and never
+    re-execs: children are fresh interpreters."""
+    n = args.gpus
+    if not args.dry:
+        import torch
+        have = torch.cuda.device_count()          # does not create a HIP context
+        if have < n:
+            print("bench.py: --gpus %d but only %d visible" % (n, have), file=sys.stderr)
+            return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    alive = set(range(n))
+    while alive:
+        for r in sorted(alive):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            alive.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                print("bench.py: rank %d exited with status %d; stopping the others" % (r, rc), file=sys.stderr)
+                for o in alive:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return worst
+
+
+# ============================================================================= workload
+def smooth_images(torch, gen, B):
     """Low-pass filtered uniform noise in [0,1] built on the device."""
     x = torch.rand((B, 3, H // 8, W // 8), device=gen.device, generator=gen)
     x = torch.nn.functional.interpolate(x, size=(H, W), mode="bicubic", align_corners=False)
@@ -57,7 +123,7 @@ def smooth_images(gen, B):
     return x.permute(0, 2, 3, 1).contiguous()
 
 
-def smooth_flow(gen, B):
+def smooth_flow(torch, gen, B):
     """Smooth field ~N(0, 8 px) plus a per-sample translation U(-20,20)."""
     x = torch.randn((B, 2, H // 32, W // 32), device=gen.device, generator=gen) * 8.0
     x = torch.nn.functional.interpolate(x, size=(H, W), mode="bicubic", align_corners=False)
@@ -66,24 +132,36 @@ def smooth_flow(gen, B):
 
 
 class Workload:
-    def __init__(self, B, dev, seed, global_batch):
+    """The synthetic batch of one rank and the step over it."""
+
+    def __init__(self, B, dev, seed, global_batch, features=True):
+        import torch
+        from unflow_amd import dist as udist
+        from unflow_amd import losses
+        self.torch = torch
         gen = torch.Generator(device=dev)
         gen.manual_seed(seed)
         self.B, self.global_batch = B, global_batch
         lrelu = torch.nn.functional.leaky_relu
-        self.fa = lrelu(torch.randn((B, FEAT_C, H8, W8), device=dev, generator=gen), 0.1)
-        self.fb = lrelu(torch.randn((B, FEAT_C, H8, W8), device=dev, generator=gen), 0.1)
-        self.top_fw = torch.randn((B, D, H8, W8), device=dev, generator=gen)
-        self.top_bw = torch.randn((B, D, H8, W8), device=dev, generator=gen)
-        self.im1 = smooth_images(gen, B)
-        self.im2 = smooth_images(gen, B)
-        self.flow_fw = smooth_flow(gen, B).requires_grad_(True)
-        self.flow_bw = (-self.flow_fw.detach() + 0.5 * smooth_flow(gen, B) * 0.1).requires_grad_(True)
+        # the generator is consumed in this order whatever `features` is, so the images and flows
+        # of a rank are the same tensors with and without the correlation inputs
+        fa = lrelu(torch.randn((B, FEAT_C, H8, W8), device=dev, generator=gen), 0.1)
+        fb = lrelu(torch.randn((B, FEAT_C, H8, W8), device=dev, generator=gen), 0.1)
+        top_fw = torch.randn((B, D, H8, W8), device=dev, generator=gen)
+        top_bw = torch.randn((B, D, H8, W8), device=dev, generator=gen)
+        if features:
+            self.fa, self.fb, self.top_fw, self.top_bw = fa, fb, top_fw, top_bw
+        del fa, fb, top_fw, top_bw
+        self.im1 = smooth_images(torch, gen, B)
+        self.im2 = smooth_images(torch, gen, B)
+        self.flow_fw = smooth_flow(torch, gen, B).requires_grad_(True)
+        self.flow_bw = (-self.flow_fw.detach() + 0.5 * smooth_flow(torch, gen, B) * 0.1).requires_grad_(True)
         self.border = losses.create_border_mask(self.im1, 0.1)
-        self.grad_buffer = torch.zeros(GRAD_BUFFER_FLOATS, device=dev)
+        self.grad_buffer = udist.FlatGradBuffer(GRAD_BUFFER_FLOATS, dev) if features else None
         self.corr_events = []   # (start, end, kind) HIP events on the launch stream
 
     def _timed(self, kind, fn, *a, **k):
+        torch = self.torch
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         r = fn(*a, **k)
@@ -91,7 +169,24 @@ class Workload:
         self.corr_events.append((s, e, kind))
         return r
 
+    def loss_leg(self):
+        """The loss half of the step: level-0 compute_losses (fused census/warp and occlusion
+        kernels) forward, backward to both flows.  tests/test_gpu_fullsize.py checks exactly
+        this call at this size against the composed HIP path and the oracle."""
+        from unflow_amd import losses
+        self.flow_fw.grad = None
+        self.flow_bw.grad = None
+        ls = losses.compute_losses(self.im1, self.im2, self.flow_fw, self.flow_bw,
+                                   border_mask=self.border, mask_occlusion="fb",
+                                   data_max_distance=3, norm_batch=self.global_batch,
+                                   terms=("ternary", "sym"))
+        ls["ternary"].backward()
+        return ls
+
     def step(self, world, bidirectional=False):
+        from unflow_amd import dist as udist
+        from unflow_amd import ops
+        torch = self.torch
         with torch.no_grad():
             if bidirectional:
                 # extension (DESIGN 4.1): corr(b, a) is a bit-exact re-indexing of corr(a, b), and one
@@ -105,74 +200,236 @@ class Workload:
                 c_bw = self._timed("corr_fwd", ops.correlation, self.fb, self.fa)
                 g_fw = self._timed("corr_bwd", ops.correlation_grad, self.top_fw, self.fa, self.fb)
                 g_bw = self._timed("corr_bwd", ops.correlation_grad, self.top_bw, self.fb, self.fa)
-        self.flow_fw.grad = None
-        self.flow_bw.grad = None
-        ls = losses.compute_losses(self.im1, self.im2, self.flow_fw, self.flow_bw,
-                                   border_mask=self.border, mask_occlusion="fb",
-                                   data_max_distance=3, norm_batch=self.global_batch,
-                                   terms=("ternary", "sym"))
-        loss = ls["ternary"]
-        loss.backward()
-        if world > 1:
-            dist.all_reduce(loss.detach(), op=dist.ReduceOp.SUM)
-            dist.all_reduce(self.grad_buffer, op=dist.ReduceOp.SUM)
-        return loss.detach(), (c_fw, c_bw, g_fw, g_bw)
+        ls = self.loss_leg()
+        loss = ls["ternary"].detach()
+        if world > 1:    # the reference's average_gradients (core/train.py:446-480) as two RCCL all-reduces
+            loss = udist.reduce_losses({"ternary": loss})["ternary"]
+            self.grad_buffer.all_reduce()
+        return loss, (c_fw, c_bw, g_fw, g_bw)
+
+    def composed_loss(self):
+        """The same loss through the UNFUSED HIP ops (image_warp -> fb_occlusion -> ternary_loss):
+        the in-run check of the fused kernels the step times."""
+        from unflow_amd import losses
+        from unflow_amd.image_warp import image_warp
+        with self.torch.no_grad():
+            npx = self.global_batch * H * W
+            m_fw, m_bw = self.border.clone(), self.border.clone()
+            losses.fb_occlusion(self.flow_fw, image_warp(self.flow_bw, self.flow_fw), m_fw)
+            losses.fb_occlusion(self.flow_bw, image_warp(self.flow_fw, self.flow_bw), m_bw)
+            return (losses.ternary_loss(self.im1, image_warp(self.im2, self.flow_fw), m_fw, 3, norm_count=npx) +
+                    losses.ternary_loss(self.im2, image_warp(self.im1, self.flow_bw), m_bw, 3, norm_count=npx))
 
 
-def cpu_baseline(n_pairs=2, threads=0):
-    """The CPU oracle (a restatement: kind "port") timed on this host over a bounded
-    sample of the same step: n_pairs 384x1280 pairs, all host threads (threads=0) or
-    the given number."""
+# ============================================================================= CPU baseline (oracle = checker + timed sample)
+def cpu_baseline(wl, n_pairs=2, runs=5):
+    """The CPU oracle (a restatement: kind "port") on the FIRST n_pairs pairs of the GPU
+    workload (same smooth fields), one warm-up + the median of `runs` timed repetitions,
+    with all host threads and with one.  The same oracle outputs double as a full-size parity
+    check of the HIP path on those pairs (loss and cost volume)."""
+    import numpy as np
     import oracle
+    from unflow_amd import losses, ops
+    torch = wl.torch
     oracle.build()
     all_threads = oracle.num_threads()
-    if threads:
+
+    def host(t, n):
+        return t[:n].detach().cpu().numpy()
+
+    def one_pass(n):
+        f0, f1, top = host(wl.fa, n), host(wl.fb, n), host(wl.top_fw, n)
+        im1, im2, ffw, fbw, border = (host(t, n) for t in (wl.im1, wl.im2, wl.flow_fw, wl.flow_bw, wl.border))
+        t0 = time.perf_counter()
+        c_first = None
+        for a, b in ((f0, f1), (f1, f0)):
+            c, p0, p1 = oracle.correlation(a, b)
+            oracle.correlation_grad(top, a, b, p0, p1)
+            c_first = c if c_first is None else c_first
+        ls, aux = oracle.compute_losses(im1, im2, ffw, fbw, border, "fb", 3, terms=("ternary", "sym"))
+        g2 = oracle.ternary_loss_grad(im1, aux["im2_warped"], aux["mask_fw"], 3)
+        oracle.image_warp_grad(g2, im2, ffw, want_im=False)
+        g1 = oracle.ternary_loss_grad(im2, aux["im1_warped"], aux["mask_bw"], 3)
+        oracle.image_warp_grad(g1, im1, fbw, want_im=False)
+        return time.perf_counter() - t0, ls, c_first
+
+    def median_time(n, threads):
         oracle.set_num_threads(threads)
-    rng = np.random.default_rng(1234)
-    f0 = rng.standard_normal((n_pairs, FEAT_C, H8, W8)).astype(np.float32)
-    f1 = rng.standard_normal((n_pairs, FEAT_C, H8, W8)).astype(np.float32)
-    top = rng.standard_normal((n_pairs, D, H8, W8)).astype(np.float32)
-    im1 = rng.uniform(size=(n_pairs, H, W, 3)).astype(np.float32)
-    im2 = rng.uniform(size=(n_pairs, H, W, 3)).astype(np.float32)
-    ffw = (rng.standard_normal((n_pairs, H, W, 2)) * 4).astype(np.float32)
-    fbw = -ffw
-    border = oracle.create_border_mask((n_pairs, H, W))
-    t0 = time.perf_counter()
-    for a, b in ((f0, f1), (f1, f0)):
-        c, p0, p1 = oracle.correlation(a, b)
-        oracle.correlation_grad(top, a, b, p0, p1)
-    _, aux = oracle.compute_losses(im1, im2, ffw, fbw, border, "fb", 3, terms=("ternary", "sym"))
-    g2 = oracle.ternary_loss_grad(im1, aux["im2_warped"], aux["mask_fw"], 3)
-    oracle.image_warp_grad(g2, im2, ffw, want_im=False)
-    g1 = oracle.ternary_loss_grad(im2, aux["im1_warped"], aux["mask_bw"], 3)
-    oracle.image_warp_grad(g1, im1, fbw, want_im=False)
-    dt = time.perf_counter() - t0
-    cores = oracle.num_threads()
+        one_pass(n)                               # warm-up (pages in the library and the thread pool)
+        times, last = [], None
+        for _ in range(runs):
+            dt, ls, c = one_pass(n)
+            times.append(dt)
+            last = (ls, c)
+        return float(np.median(times)), times, last
+
+    t_all, times_all, (ls, c_ref) = median_time(n_pairs, all_threads)
+    t_one, times_one, _ = median_time(1, 1)
     oracle.set_num_threads(all_threads)
-    return {"value": n_pairs / dt, "unit": "image-pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d pairs of 384x1280 (same step: 2 corr fwd+bwd, level-0 loss fwd+bwd), %.1f s, "
-                      "OpenMP C restatement oracle/unflow_oracle.c" % (n_pairs, dt)}
+
+    # parity of the HIP path on the same pairs, at full size
+    with torch.no_grad():
+        c_gpu = ops.correlation(wl.fa[:n_pairs], wl.fb[:n_pairs]).cpu().numpy()
+    corr_err = float(np.abs(c_gpu - c_ref).max())
+    ffw = wl.flow_fw[:n_pairs].detach().clone().requires_grad_(True)
+    fbw = wl.flow_bw[:n_pairs].detach().clone().requires_grad_(True)
+    got = losses.compute_losses(wl.im1[:n_pairs], wl.im2[:n_pairs], ffw, fbw, border_mask=wl.border[:n_pairs],
+                                mask_occlusion="fb", data_max_distance=3, terms=("ternary", "sym"))
+    rel = {k: abs(float(got[k]) - ls[k]) / abs(ls[k]) for k in ("ternary", "sym")}
+    if corr_err > 1e-5 or rel["ternary"] > 2e-4 or rel["sym"] > 2e-4:
+        raise AssertionError("bench: HIP path and CPU oracle disagree at full size: corr max abs err %.3g, "
+                             "loss rel err %s" % (corr_err, rel))
+    return {"value": n_pairs / t_all, "unit": "image-pairs/s", "cores": all_threads, "kind": "port",
+            "sample": "the first %d pairs of the GPU workload (384x1280, same smooth fields; same step: 2 corr fwd+bwd, "
+                      "level-0 loss fwd+bwd), 1 warm-up + median of %d runs (%.2f s each), OpenMP C restatement "
+                      "oracle/unflow_oracle.c" % (n_pairs, runs, t_all),
+            "runs_s": [round(t, 3) for t in times_all],
+            "single_thread": {"value": 1.0 / t_one, "unit": "image-pairs/s", "cores": 1,
+                              "sample": "the first pair, 1 warm-up + median of %d runs" % runs,
+                              "runs_s": [round(t, 3) for t in times_one]},
+            "parity_check": {"pairs": n_pairs, "corr_fwd_max_abs_err": corr_err, "loss_rel_err": rel,
+                             "loss_oracle": {k: float(ls[k]) for k in ("ternary", "sym")}}}
+
+
+# ============================================================================= measurements beside the headline
+def event_time(torch, fn, n=5, warm=1):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+def stream_copy_gbs(torch, dev, gib=1):
+    """Rate of the library's hand-written float4 streaming copy over `gib` GiB (read + write bytes)."""
+    import ctypes
+    from unflow_amd import _lib
+    n = gib * 256 * 1024 * 1024
+    a = torch.empty(n, device=dev)
+    b = torch.empty_like(a)
+    a.normal_()
+    lib = _lib.load()
+
+    def go():
+        _lib.check(lib.unflow_stream_copy(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                          ctypes.c_size_t(n * 4), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    ms = event_time(torch, go, n=5, warm=2)
+    assert torch.equal(a[:4096], b[:4096]) and torch.equal(a[-4096:], b[-4096:])
+    return 2 * n * 4 / (ms * 1e-3) / 1e9
+
+
+def warps_roofline(wl, copy_gbs):
+    """In-run HIP-event timings of the HBM-bound warps at the step's batch (north_star names
+    backward-warp): algorithmic bytes / time, as fractions of the measured copy and of 8 TB/s."""
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp, image_warp_grad
+    torch = wl.torch
+    npx = wl.B * H * W
+    ffw = wl.flow_fw.detach()
+    g3 = torch.randn_like(wl.im2)
+    rows = {}
+    for name, fn, bpp in (("backward_warp", lambda: ops.backward_warp(wl.im2, ffw), 32),
+                          ("backward_warp_grad", lambda: ops.backward_warp_grad(g3, wl.im2, ffw), 40),
+                          ("image_warp", lambda: image_warp(wl.im2, ffw), 32),
+                          ("image_warp_grad_flow", lambda: image_warp_grad(g3, wl.im2, ffw, False, True), 40)):
+        ms = event_time(torch, fn, n=10, warm=2)
+        gbs = npx * bpp / (ms * 1e-3) / 1e9
+        rows[name] = {"ms": ms, "bytes_per_px": bpp, "gbs": gbs, "frac_of_copy": gbs / copy_gbs,
+                      "frac_of_8TBs": gbs / HBM_PEAK_GBS}
+    return rows
+
+
+def kitti_config_step(wl):
+    """The reference's default KITTI loss (config_template/config.ini:79,98,123,166-174): 5-level
+    pyramid H/4..H/64, ternary + 3 smooth_2nd + 0.2 fb + 12.4 occ, fb occlusion masks, fwd+bwd to
+    every level's flows -- eager and as one HIP graph (informational, never `value`)."""
+    from unflow_amd import graph as ugraph
+    from unflow_amd import unsupervised
+    torch = wl.torch
+    dev = wl.im1.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    B = wl.B
+    pf = [(torch.randn((B, H >> (2 + i), W >> (2 + i), 2), device=dev, generator=g) * 0.3).requires_grad_(True)
+          for i in range(5)]
+    pb = [(-f.detach() + 0.02 * torch.randn(f.shape, device=dev, generator=g)).requires_grad_(True) for f in pf]
+
+    def step():
+        loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, KITTI)
+        return (loss,) + torch.autograd.grad(loss, pf + pb)
+    eager_ms = event_time(torch, step, n=5, warm=2)
+    gs = ugraph.GraphedStep(step)
+    graph_ms = event_time(torch, gs.replay, n=10, warm=2)
+    return {"note": "NOT the headline: 5-level pyramid loss of the reference's [train_kitti] config "
+                    "(ternary + 3*smooth_2nd + 0.2*fb + 12.4*occ, mask_occlusion=fb), fwd+bwd, batch %d" % B,
+            "eager_ms": eager_ms, "graph_ms": graph_ms, "pairs_per_s_graph": B / (graph_ms * 1e-3),
+            "loss": float(step()[0])}
+
+
+def traffic_record():
+    """HBM bytes of the dominant kernel from PMC counters.  bench.py cannot sit under
+    ``rocprofv3 --pmc`` and time itself, so the counters come from a separate pass
+    (tools/traffic_pmc.sh -> profiles/r02_traffic.json); the record carries the hash of the
+    kernel source it was collected on and is only used when that is the source of this build."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    src = os.path.join(ROOT, "unflow_amd", "csrc", "correlation_mfma.hip")
+    if not (os.path.exists(path) and os.path.exists(src)):
+        return None, None
+    with open(path) as fh:
+        rec = json.load(fh)
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    if rec.get("kernel_source_sha16") != sha:
+        return None, {"file": "profiles/r02_traffic.json", "stale": True,
+                      "note": "collected on another version of correlation_mfma.hip: not reported"}
+    return rec["corr_bwd_both_launches"]["hbm_bytes"], {
+        "file": "profiles/r02_traffic.json", "kernel_source_sha16": sha,
+        "how": "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/traffic_pmc.sh), FETCH_SIZE doubled "
+               "(gfx950), per call = both gradient launches; not measured in this run"}
+
+
+# ============================================================================= main
+def run_dry(args):
+    """Launch-path rehearsal without a GPU: rendezvous, one all-reduce, one JSON line."""
+    import torch
+    from unflow_amd import dist as udist
+    if os.environ.get("UNFLOW_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):   # test hook: a rank that dies
+        sys.exit(17)
+    rank, world = udist.init_process_group(args.backend or "gloo")
+    t = torch.tensor([float(rank + 1)])
+    udist.all_reduce_sum_(t)
+    assert float(t) == world * (world + 1) / 2
+    start, stop = udist.shard_range(args.batch * world, rank, world)
+    assert stop - start == args.batch
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "value": 0.0, "n_gpus": world, "dry": True,
+                          "gpus_requested": args.gpus, "backend": args.backend or "gloo",
+                          "allreduce_check": float(t)}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="image pairs per GPU (weak scaling)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-single-thread", action="store_true",
-                    help="also time the CPU oracle on ONE thread (one pair, about a minute; SURVEY 8d)")
-    ap.add_argument("--breakdown", action="store_true", help="also print per-op timings to stderr")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.dry:
+        sys.exit(run_dry(args))
 
-    rank = int(os.environ.get("RANK", "0"))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from unflow_amd import dist as udist
+
+    rank, world = udist.init_process_group(args.backend)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != max(args.gpus, 1) and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus=%d"
+              % (args.gpus, world, world), file=sys.stderr)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -187,28 +444,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = wl.step(world)
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # for information only (never `value`): the same step with the bidirectional-correlation extension
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step(world, bidirectional=True)
-    fence()
-    dt_bidir = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([dt_bidir], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt_bidir = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0)
 
     # dominant kernel: correlation backward (3.47 GFLOP/pair, f32 MFMA); averaged over the timed region
     per_kind = {}
@@ -217,31 +465,30 @@ def main():
     bwd_ms = float(np.mean(per_kind["corr_bwd"]))
     fwd_ms = float(np.mean(per_kind["corr_fwd"]))
 
+    dt_bidir = None
+    if not args.no_extras:
+        # for information only (never `value`): the same step with the bidirectional-correlation extension
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step(world, bidirectional=True)
+        fence()
+        dt_bidir = max_over_ranks(time.perf_counter() - t1)
+
+    # in-run check of the fused loss kernels the step times (every rank checks its own shard)
+    fused = float(wl.loss_leg()["ternary"])
+    composed = float(wl.composed_loss())
+    if not abs(fused - composed) <= 1e-6 * abs(composed):
+        raise AssertionError("bench: fused loss %.9g != composed HIP loss %.9g" % (fused, composed))
+
     if args.breakdown and rank == 0:
         breakdown(wl, fwd_ms, bwd_ms)
 
     if rank == 0:
         pairs = args.batch * world * args.steps
         achieved_tf = CORR_BWD_FLOP * args.batch / (bwd_ms * 1e-3) / 1e12
-        # HBM bytes of that launch from PMC counters are collected offline (bench.py cannot
-        # run under rocprofv3 --pmc and time itself): tools/traffic_pmc.sh -> profiles/r01_traffic.json
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and args.batch == 32:
-            with open(tpath) as fh:
-                traffic = json.load(fh)["corr_bwd_both_launches"]["hbm_bytes"]
-        # measured copy roofline of this GPU (1 GiB device-to-device)
-        a = torch.empty(256 * 1024 * 1024, device=dev)
-        b = torch.empty_like(a)
-        b.copy_(a)
-        s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s0.record()
-        for _ in range(3):
-            b.copy_(a)
-        e0.record()
-        torch.cuda.synchronize()
-        copy_gbs = 3 * 2 * a.numel() * 4 / (s0.elapsed_time(e0) * 1e-3) / 1e9
-        del a, b
+        traffic, traffic_src = traffic_record() if args.batch == 32 else (None, None)
+        copy_gbs = stream_copy_gbs(torch, dev)
         out = {
             "metric": "image-pairs/sec (corr+warp+census fwd+bwd) at 384x1280 b32",
             "value": pairs / dt, "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps,
@@ -251,47 +498,56 @@ def main():
                                    "[B,256,48,160] + level-0 compute_losses (4 image_warp evaluated inside the census and fb-occlusion "
                                    "kernels, 2 forward_warp + sym term, 2 ternary 7x7) fwd+bwd" % args.batch,
                        "global_batch": args.batch * world, "height": H, "width": W,
-                       "parallelism": "batch-sharded x%d, all-reduce of loss + 156.7 MB grad buffer" % world},
+                       "parallelism": "batch-sharded x%d (one process per GPU), all-reduce of loss + 156.7 MB grad buffer" % world,
+                       "world_size": world, "backend": dist.get_backend() if world > 1 else None},
             "roofline": {"bound": "mfma",
                          "kernel": "correlation backward: corr_mfma_bwd_kernel, both gradient launches of one call",
                          "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP32_MATRIX_PEAK_TF, "traffic": traffic,
-                         "measured_copy_gbs": copy_gbs,
+                         "frac": achieved_tf / FP32_MATRIX_PEAK_TF,
+                         "frac_basis": "HIP events around the call on the launch stream, mean over the timed region "
+                                       "(rocprofv3 kernel averages of the same command: profiles/r02_bench_kernel_stats.csv)",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "stream_copy_gbs": copy_gbs,
                          "avg_launch_ms": bwd_ms,
                          "hbm_gbs": CORR_BWD_BYTES * args.batch / (bwd_ms * 1e-3) / 1e9,
                          "hbm_frac_of_8TBs": CORR_BWD_BYTES * args.batch / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "corr_fwd": {"avg_launch_ms": fwd_ms,
                                       "tflops": CORR_FWD_FLOP * args.batch / (fwd_ms * 1e-3) / 1e12,
+                                      "frac": CORR_FWD_FLOP * args.batch / (fwd_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TF,
                                       "hbm_gbs": CORR_FWD_BYTES * args.batch / (fwd_ms * 1e-3) / 1e9}},
             "loss": float(loss),
+            "loss_check": {"fused": fused, "composed_hip": composed,
+                           "note": "rank 0's shard through the fused kernels vs the unfused HIP ops, asserted to 1e-6; "
+                                   "the oracle check on the first pairs is in cpu_baseline.parity_check"},
         }
-        out["extension_bidirectional_correlation"] = {
-            "note": "NOT the headline: the same step when the caller obtains the (b,a) cost volume as a bit-exact "
-                    "re-indexing of the (a,b) one and runs one backward call for both directions "
-                    "(ops.correlation_bidirectional, DESIGN.md 4.1)",
-            "ms_per_step": dt_bidir / args.steps * 1e3, "value": pairs / dt_bidir, "unit": "image-pairs/s"}
+        if not args.no_extras:
+            out["roofline"]["warps"] = dict(
+                warps_roofline(wl, copy_gbs), bound="hbm",
+                note="algorithmic bytes / HIP-event time at B=%d; frac_of_copy is against stream_copy_gbs "
+                     "(hand-written float4 copy, 1 GiB), frac_of_8TBs against the nominal HBM peak" % args.batch)
+            out["extension_bidirectional_correlation"] = {
+                "note": "NOT the headline: the same step when the caller obtains the (b,a) cost volume as a bit-exact "
+                        "re-indexing of the (a,b) one and runs one backward call for both directions "
+                        "(ops.correlation_bidirectional, DESIGN.md 4.1)",
+                "ms_per_step": dt_bidir / args.steps * 1e3, "value": pairs / dt_bidir, "unit": "image-pairs/s"}
+            out["kitti_config_step"] = kitti_config_step(wl)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            if args.cpu_single_thread:
-                out["cpu_baseline"]["single_thread"] = cpu_baseline(n_pairs=1, threads=1)
+            out["cpu_baseline"] = cpu_baseline(wl, runs=args.cpu_runs)
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
 def breakdown(wl, fwd_ms, bwd_ms):
     """Per-op device time (HIP events on the launch stream), to stderr."""
+    from unflow_amd import losses, ops
     from unflow_amd.image_warp import image_warp, image_warp_grad
+    torch = wl.torch
 
     def timeit(fn, n=5):
-        fn()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(n):
-            fn()
-        e.record()
-        torch.cuda.synchronize()
-        return s.elapsed_time(e) / n
+        return event_time(torch, fn, n=n, warm=1)
 
     B = wl.B
     npx = B * H * W
@@ -319,6 +575,8 @@ def breakdown(wl, fwd_ms, bwd_ms):
     rows.append(("image_warp C2", timeit(lambda: image_warp(fbw, ffw)), npx * 24))
     rows.append(("image_warp_grad flow C3", timeit(lambda: image_warp_grad(g3, wl.im2, ffw, False, True)), npx * 40))
     rows.append(("image_warp_grad im C3", timeit(lambda: image_warp_grad(g3, wl.im2, ffw, True, False)), npx * 32))
+    g2 = torch.randn_like(ffw)
+    rows.append(("image_warp_grad im C2", timeit(lambda: image_warp_grad(g2, fbw, ffw, True, False)), npx * 24))
     rows.append(("backward_warp C3", timeit(lambda: ops.backward_warp(wl.im2, ffw)), npx * 32))
     rows.append(("backward_warp_grad C3", timeit(lambda: ops.backward_warp_grad(g3, wl.im2, ffw)), npx * 40))
     rows.append(("forward_warp", timeit(lambda: ops.forward_warp(ffw)), npx * 12))
@@ -343,36 +601,23 @@ def breakdown(wl, fwd_ms, bwd_ms):
     gl = losses.gradient_loss(wl.im1, x, wl.border)
     rows.append(("gradient_loss fwd", timeit(lambda: losses.gradient_loss(wl.im1, x, wl.border)), npx * 28))
     rows.append(("gradient_loss bwd", timeit(lambda: torch.autograd.grad(gl, x, retain_graph=True)), npx * 40))
-    # the 5-level pyramid variant with the reference's [train_kitti] weights
-    from unflow_amd import unsupervised
-    kitti = dict(pyramid_loss=True, border_mask=True, mask_occlusion="fb", ternary_weight=1.0,
-                 smooth_2nd_weight=3.0, fb_weight=0.2, occ_weight=12.4)
+    rows.append(("loss leg of the step (compute_losses ternary+sym fwd+bwd)", timeit(wl.loss_leg), 0))
+    k = kitti_config_step(wl)
+    rows.append(("pyramid loss, 5 levels H/4..H/64, kitti weights, fwd+bwd", k["eager_ms"], 0))
+    rows.append(("  the same as one HIP graph (unflow_amd.graph.GraphedStep)", k["graph_ms"], 0))
+    from unflow_amd import flownet
     g = torch.Generator(device=ffw.device)
     g.manual_seed(7)
-    pf = [(torch.randn((B, H >> (2 + i), W >> (2 + i), 2), device=ffw.device, generator=g) * 0.3).requires_grad_(True)
-          for i in range(5)]
-    pb = [(-f.detach() + 0.02 * torch.randn(f.shape, device=ffw.device, generator=g)).requires_grad_(True) for f in pf]
-
-    def pyr():
-        loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, kitti)
-        loss.backward()
-    rows.append(("pyramid loss, 5 levels H/4..H/64, kitti weights, fwd+bwd", timeit(pyr), 0))
-    from unflow_amd import graph as ugraph
-
-    def pyr_step():
-        loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, kitti)
-        return (loss,) + torch.autograd.grad(loss, pf + pb)
-    gs = ugraph.GraphedStep(pyr_step)
-    rows.append(("  the same as one HIP graph (unflow_amd.graph.GraphedStep)", timeit(gs.replay), 0))
-    from unflow_amd import flownet
     flr = torch.randn((B, H // 4, W // 4, 2), device=ffw.device, generator=g) * 0.3
     rows.append(("stacked_inputs (resize+warp+abs+concat, 14 ch)", timeit(lambda: flownet.stacked_inputs(wl.im1, wl.im2, flr)), npx * 80))
     rows.append(("fb_occlusion", timeit(lambda: losses.fb_occlusion(ffw, fbw)), npx * 28))
     rows.append(("downsample x2 C3", timeit(lambda: ops.downsample(wl.im1, 2)), npx * 15))
     a = torch.empty(256 * 1024 * 1024, device=ffw.device)
     b = torch.empty_like(a)
-    cp = timeit(lambda: b.copy_(a))
-    rows.append(("d2d copy 1 GiB (measured HBM roofline)", cp, 2 * a.numel() * 4))
+    rows.append(("d2d torch copy_ 1 GiB", timeit(lambda: b.copy_(a)), 2 * a.numel() * 4))
+    del a, b
+    gbs = stream_copy_gbs(torch, ffw.device)
+    rows.append(("unflow_stream_copy 1 GiB (measured HBM roofline)", 2 * 2 ** 30 / gbs / 1e6, 2 * 2 ** 30))
     for name, ms, nbytes in rows:
         print("%-42s %9.3f ms  %8.1f GB/s algorithmic" % (name, ms, nbytes / ms / 1e6), file=sys.stderr)
 

@@ -14,7 +14,9 @@
  *    x displacement (ops/backward_warp_op.cu.cc:27-28).
  *  - `stream` is a hipStream_t (NULL = the default stream).  Work is enqueued
  *    asynchronously; no entry point synchronises, allocates device memory or
- *    keeps state between calls.  The library is re-entrant.
+ *    keeps state between calls.  The library is re-entrant.  (The only thing
+ *    remembered is, per device, that a kernel needing more than 64 KiB of LDS has
+ *    been granted it -- hipFuncSetAttribute is a per-device setting.)
  *  - Return value: UNFLOW_OK, or an error code with a message retrievable
  *    through unflow_last_error() (thread local).  UNFLOW_ERR_INVALID_ARGUMENT
  *    messages are the reference's OP_REQUIRES strings.
@@ -34,12 +36,17 @@ extern "C" {
 #define UNFLOW_ERR_INVALID_ARGUMENT 1 /* tf errors::InvalidArgument */
 #define UNFLOW_ERR_LAUNCH 2           /* hipGetLastError() after a launch */
 
-#define UNFLOW_ABI_VERSION 1
+#define UNFLOW_ABI_VERSION 2
 
 typedef void *unflow_stream_t; /* hipStream_t */
 
 int unflow_abi_version(void);
 const char *unflow_last_error(void);
+
+/* Measurement helper, not part of the reference's path: dst[0..bytes) = src[0..bytes) with a
+ * hand-written 16-byte-per-lane streaming copy.  bench.py prices the HBM-bound kernels
+ * (the warps) against the rate of this copy over >= 1 GiB, next to the nominal 8 TB/s. */
+int unflow_stream_copy(const void *src, void *dst, size_t bytes, unflow_stream_t stream);
 
 /* ---------------------------------------------------------------- correlation
  * Geometry of CorrelationState (ops/correlation_op.h:28-51).
@@ -110,10 +117,11 @@ int unflow_downsample_fwd(const float *images, float *output, int B, int H, int 
  *   dldd:      optional [B,H,W] map saved for the backward pass
  *              (mask' * d charbonnier / d dist / norm_count); may be NULL.
  *   dist:      optional [B,H,W,1] per-pixel distance (for tests); may be NULL.
- *   workspace: unflow_reduce_workspace_floats(B*H*W) floats.
+ *   workspace: unflow_reduce_workspace_floats(B, H, W) floats (one partial sum per
+ *              workgroup of the loss kernels: a few thousand, not one per pixel).
  *   norm_count: the charbonnier normalisation (losses.py:311-312); 0 means the
  *              local B*H*W, a batch shard passes the GLOBAL pixel count. */
-size_t unflow_reduce_workspace_floats(long long n_pixels);
+size_t unflow_reduce_workspace_floats(int B, int H, int W);
 int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped, const float *mask,
                             float *loss, float *dldd, float *dist, float *workspace, int B, int H,
                             int W, int max_distance, long long norm_count, unflow_stream_t stream);
@@ -219,8 +227,9 @@ int unflow_gradient_delta(const float *im1, const float *im2_warped, float *diff
  * out = (add ? add : 0) + flip(in); in, add, out [B,D,H,W].  The map is its own inverse, so
  * top_fw + flip(top_bw) is the upstream gradient of the first volume that makes ONE
  * unflow_correlation_bwd call return the summed gradients of both directions.
- * Needs kernel_size 1, stride_1 1, pad == max_displacement. */
-int unflow_correlation_flip(const float *in, const float *add, float *out, int B, int H, int W,
+ * Needs kernel_size 1, stride_1 1, pad == max_displacement; D (the number of displacement
+ * planes of the volumes) must be the out_channels the attrs imply. */
+int unflow_correlation_flip(const float *in, const float *add, float *out, int B, int D, int H, int W,
                             int kernel_size, int max_displacement, int pad, int stride_1,
                             int stride_2, unflow_stream_t stream);
 
@@ -271,6 +280,14 @@ int unflow_resize_bilinear_fwd(const float *in, float *out, int B, int h, int w,
                                float mult, unflow_stream_t stream);
 int unflow_resize_bilinear_bwd(const float *gout, float *gin, int B, int h, int w, int H, int W, int C,
                                float mult, unflow_stream_t stream);
+
+/* tf.image.resize_area (TensorFlow 1.x, align_corners=False; third-party): the odd-extent
+ * branch of core/util.downsample (src/e2eflow/core/util.py:23-28), which the loss pyramid
+ * (core/unsupervised.py:97-99,143-145) reaches at levels whose height or width is odd.
+ * in [B,H,W,C] -> out [B,out_h,out_w,C], box average with fractional coverage weights.
+ * Not differentiable on the reference's path (inputs are images and masks). */
+int unflow_resize_area_fwd(const float *in, float *out, int B, int H, int W, int C, int out_h,
+                           int out_w, unflow_stream_t stream);
 
 #ifdef __cplusplus
 }

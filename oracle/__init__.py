@@ -156,6 +156,24 @@ def downsample(images, scale):
     return out
 
 
+def resize_area(images, height, width):
+    """tf.image.resize_area (TF 1.x, align_corners=False); assumption A3, parity unpinned."""
+    images = _f32(images)
+    B, H, W, C = images.shape
+    out = np.empty((B, height, width, C), np.float32)
+    lib().oracle_resize_area_fwd(_p(images), _p(out), B, H, W, C, height, width)
+    return out
+
+
+def util_downsample(tensor, num):
+    """core/util.downsample (src/e2eflow/core/util.py:23-28): the op when both extents are
+    even (it tests % 2 whatever num is), tf.image.resize_area otherwise."""
+    _, height, width, _ = np.shape(tensor)
+    if height % 2 == 0 and width % 2 == 0:
+        return downsample(tensor, num)
+    return resize_area(tensor, int(height / num), int(width / num))
+
+
 def image_warp(im, flow):
     im, flow = _f32(im), _f32(flow)
     B, H, W, C = im.shape
@@ -440,7 +458,7 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params):
         im1_s, im2_s, mask_s = _f32(im1_norm), _f32(im2_norm), _f32(border_mask)
         final_flow_scale = 5.0 * 4
     else:
-        im1_s, im2_s, mask_s = downsample(im1_norm, 4), downsample(im2_norm, 4), downsample(border_mask, 4)
+        im1_s, im2_s, mask_s = (util_downsample(t, 4) for t in (im1_norm, im2_norm, border_mask))
         final_flow_scale = 5.0
     combined_losses = {k: 0.0 for k in LOSSES}
     combined_loss = 0.0
@@ -458,5 +476,5 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params):
                 combined_losses[k] += layer_weights[i] * losses[k]
         combined_loss += layer_weights[i] * layer_loss
         if n + 1 < len(pairs):
-            im1_s, im2_s, mask_s = downsample(im1_s, 2), downsample(im2_s, 2), downsample(mask_s, 2)
+            im1_s, im2_s, mask_s = (util_downsample(t, 2) for t in (im1_s, im2_s, mask_s))
     return combined_loss, combined_losses

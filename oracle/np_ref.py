@@ -243,6 +243,26 @@ def gradient_loss(im1, im2_warped, mask):
     return (ex.sum() + ey.sum()) / (B * H * W * 6)
 
 
+def resize_area(images, out_h, out_w):
+    """tf.image.resize_area (TF 1.x, align_corners=False) as an exact overlap integral in
+    float64: out[y, x] = mean of the input over the box [y*sy, (y+1)*sy) x [x*sx, (x+1)*sx),
+    the input being piecewise constant on unit pixels and clamped at the border --
+    independent of the loop/weight formulation the C oracle restates."""
+    a = np.asarray(images, np.float64)
+    B, H, W, C = a.shape
+
+    def overlap(n_in, n_out):
+        s = n_in / n_out
+        m = np.zeros((n_out, n_in))
+        for o in range(n_out):
+            lo, hi = o * s, (o + 1) * s
+            for i in range(int(np.floor(lo)), int(np.ceil(hi))):
+                m[o, min(max(i, 0), n_in - 1)] += max(0.0, min(hi, i + 1) - max(lo, i))
+        return m / s
+    my, mx = overlap(H, out_h), overlap(W, out_w)
+    return np.einsum("yh,bhwc,xw->byxc", my, a, mx)
+
+
 def numeric_grad(fn, x, eps=1e-3):
     """Central-difference gradient of scalar fn wrt array x (float64)."""
     x = np.array(x, np.float64)

@@ -29,6 +29,9 @@
  *                             -> image_warp -> abs -> concat); tf.image.resize_bilinear
  *                             itself is third-party: TF 1.x align_corners=False
  *                             semantics restated (assumption A2, PARITY UNPINNED)
+ *   oracle_resize_area_fwd    src/e2eflow/core/util.py:23-28 (odd-extent branch of
+ *                             downsample); tf.image.resize_area is third-party:
+ *                             TF 1.x semantics restated (assumption A3, PARITY UNPINNED)
  *   oracle_create_*_mask      src/e2eflow/core/losses.py:325-366
  *   oracle_fb_occlusion       src/e2eflow/core/losses.py:38-51
  *
@@ -1074,6 +1077,50 @@ void oracle_resize_bilinear_fwd(const float *in, float *out, int B, int h, int w
           const float top = tl + (tr - tl) * lx;
           const float bot = bl + (br - bl) * lx;
           out[(((size_t)b * H + y) * W + x) * C + c] = (top + (bot - top) * ly) * mult;
+        }
+      }
+    }
+}
+
+/* ---------------------------------------------------------------------------
+ * tf.image.resize_area, TensorFlow 1.x, align_corners=False -- the odd-extent
+ * branch of core/util.downsample (src/e2eflow/core/util.py:23-28).  Third-party
+ * (TensorFlow is not vendored; README.md:83 "at least version 1.7", unpinned);
+ * its published algorithm (resize_area_op.cc), ASSUMPTION A3, PARITY UNPINNED:
+ *   scale = in_size / (float)out_size
+ *   rows i = floor(y*scale) .. ceil((y+1)*scale)-1, weight
+ *     i < in_y ? (i+1 > in_y1 ? scale : i+1 - in_y) : (i+1 > in_y1 ? in_y1 - i : 1)
+ *   (columns likewise), indices clamped to the image; per row sum over x
+ *   (first and last column weighted, inner columns weight 1), rows combined with
+ *   their weights, result times 1/(scale_y*scale_x).
+ * ------------------------------------------------------------------------- */
+static float area_weight(int i, float lo, float hi, float scale) {
+  return (float)i < lo ? ((float)(i + 1) > hi ? scale : (float)(i + 1) - lo) : ((float)(i + 1) > hi ? hi - (float)i : 1.0f);
+}
+static int bound_index(int v, int n) { return v < 0 ? 0 : (v > n - 1 ? n - 1 : v); }
+
+void oracle_resize_area_fwd(const float *in, float *out, int B, int H, int W, int C, int oh, int ow) {
+  const float sy = (float)H / (float)oh, sx = (float)W / (float)ow;
+  const float norm = 1.0f / (sy * sx);
+  for (int b = 0; b < B; b++)
+    for (int y = 0; y < oh; y++) {
+      const float in_y = (float)y * sy, in_y1 = (float)(y + 1) * sy;
+      const int y0 = (int)floorf(in_y), y1 = (int)ceilf(in_y1);
+      for (int x = 0; x < ow; x++) {
+        const float in_x = (float)x * sx, in_x1 = (float)(x + 1) * sx;
+        const int x0 = (int)floorf(in_x), x1 = (int)ceilf(in_x1);
+        for (int c = 0; c < C; c++) {
+          float sum = 0.f;
+          for (int i = y0; i < y1; i++) {
+            const float *row = in + (((size_t)b * H + bound_index(i, H)) * W) * C + c;
+            float sum_y = row[(size_t)bound_index(x0, W) * C] * area_weight(x0, in_x, in_x1, sx);
+            if (x0 + 1 != x1) {
+              for (int j = x0 + 1; j < x1 - 1; j++) sum_y += row[(size_t)bound_index(j, W) * C];
+              sum_y += row[(size_t)bound_index(x1 - 1, W) * C] * area_weight(x1 - 1, in_x, in_x1, sx);
+            }
+            sum += sum_y * area_weight(i, in_y, in_y1, sy);
+          }
+          out[(((size_t)b * oh + y) * ow + x) * C + c] = sum * norm;
         }
       }
     }

@@ -77,3 +77,38 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def _run_bench(*flags, env_extra=None):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), capture_output=True,
+                         text=True, timeout=300, env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_flag_spawns_ranks():
+    """`bench.py --gpus 2` with no launcher environment starts two fresh ranks itself (the parent
+    never touches the GPU), they rendezvous and rank 0 prints ONE line with n_gpus = 2.  --dry
+    skips the GPU work so the launch path runs here (gloo)."""
+    out, lines = _run_bench("--gpus", "2", "--backend", "gloo", "--dry")
+    assert out.returncode == 0, out.stderr
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["gpus_requested"] == 2
+    assert lines[0]["allreduce_check"] == 3.0
+    out3, lines3 = _run_bench("--gpus", "3", "--backend", "gloo", "--dry")
+    assert out3.returncode == 0 and lines3[0]["n_gpus"] == 3
+
+
+def test_bench_under_a_launcher_takes_ranks_from_env():
+    """Under torch.distributed.run (WORLD_SIZE set) bench.py does not spawn: one process, one rank."""
+    out, lines = _run_bench("--gpus", "2", "--dry", env_extra=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert out.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1 and lines[0]["gpus_requested"] == 2
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that dies takes the launch down with a non-zero status (no hang, no silent success)."""
+    out, lines = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", env_extra={"UNFLOW_BENCH_FAIL_RANK": "1"})
+    assert out.returncode != 0 and not lines

@@ -177,3 +177,95 @@ def test_cfg5_shapes_fp32(dev):
     im2 = torch.rand((16, 768, 1280, 3), device=dev, generator=g)
     blk = flownet.stacked_inputs(im1, im2, torch.zeros((16, 192, 320, 2), device=dev))
     assert torch.equal(blk, torch.cat([im1, im2, torch.zeros_like(flow), im2, (im2 - im1).abs()], 3))
+
+
+def test_bench_loss_leg_cfg3(oracle_mod, dev):
+    """cfg3, the path bench.py times: exactly ``bench.Workload.loss_leg`` at 32x384x1280 --
+    ``compute_losses(..., 'fb', 3, terms=('ternary','sym'))`` through the warp-fused pair-symmetric
+    census kernels and the warp-fused occlusion kernel, forward and backward to both flows.
+    (i) against the composed HIP path (image_warp -> fb_occlusion -> ternary_loss / forward_warp ->
+    charbonnier) on the whole batch: loss 1e-6, flow gradients 1e-5 of their scale;
+    (ii) one pair against the CPU oracle at the tolerances of test_compute_losses_vs_oracle."""
+    import bench
+    from unflow_amd import losses
+    from unflow_amd.image_warp import image_warp
+    from unflow_amd.ops import forward_warp
+    B = 32
+    wl = bench.Workload(B, dev, seed=1234, global_batch=B, features=False)
+    ls = wl.loss_leg()
+    fused = float(ls["ternary"])
+    g_fw, g_bw = wl.flow_fw.grad.clone(), wl.flow_bw.grad.clone()
+    assert np.isfinite(fused) and torch.isfinite(g_fw).all() and torch.isfinite(g_bw).all()
+
+    # (i) the same quantities through the unfused ops
+    npx = B * H * W
+    ffw = wl.flow_fw.detach().clone().requires_grad_(True)
+    fbw = wl.flow_bw.detach().clone().requires_grad_(True)
+    m_fw, m_bw = wl.border.clone(), wl.border.clone()
+    losses.fb_occlusion(ffw, image_warp(fbw.detach(), ffw.detach()), m_fw)
+    losses.fb_occlusion(fbw, image_warp(ffw.detach(), fbw.detach()), m_bw)
+    composed = (losses.ternary_loss(wl.im1, image_warp(wl.im2, ffw), m_fw, 3, norm_count=npx) +
+                losses.ternary_loss(wl.im2, image_warp(wl.im1, fbw), m_bw, 3, norm_count=npx))
+    composed.backward()
+    np.testing.assert_allclose(fused, float(composed), rtol=1e-6)
+    assert float(wl.composed_loss()) == float(composed)           # what bench.py asserts in every run
+    for got, want in ((g_fw, ffw.grad), (g_bw, fbw.grad)):
+        scale = float(want.abs().max())
+        assert scale > 0
+        assert float((got - want).abs().max()) <= 1e-5 * scale
+    sym = (losses.charbonnier_loss((1 - m_fw) - (forward_warp(fbw.detach()) < losses.DISOCC_THRESH).float(), norm_count=npx) +
+           losses.charbonnier_loss((1 - m_bw) - (forward_warp(ffw.detach()) < losses.DISOCC_THRESH).float(), norm_count=npx))
+    np.testing.assert_allclose(float(ls["sym"]), float(sym), rtol=1e-6)
+    del ffw, fbw, composed, m_fw, m_bw
+
+    # (ii) pair 5 alone against the oracle (about a second of CPU)
+    i = 5
+    host = lambda t: t[i:i + 1].detach().cpu().numpy()
+    im1, im2, f_fw, f_bw, border = (host(t) for t in (wl.im1, wl.im2, wl.flow_fw, wl.flow_bw, wl.border))
+    want, waux = oracle_mod.compute_losses(im1, im2, f_fw, f_bw, border, "fb", 3, terms=("ternary", "sym"))
+    tfw = wl.flow_fw[i:i + 1].detach().clone().requires_grad_(True)
+    tbw = wl.flow_bw[i:i + 1].detach().clone().requires_grad_(True)
+    got = losses.compute_losses(wl.im1[i:i + 1], wl.im2[i:i + 1], tfw, tbw, border_mask=wl.border[i:i + 1],
+                                mask_occlusion="fb", data_max_distance=3, terms=("ternary", "sym"))
+    # 491 520 pixels: a threshold pixel that flips moves the scalar by 2e-6, so the scalars hold 1e-5
+    np.testing.assert_allclose(float(got["ternary"]), want["ternary"], rtol=1e-5)
+    np.testing.assert_allclose(float(got["sym"]), want["sym"], rtol=1e-5)
+    got["ternary"].backward()
+    gim2 = oracle_mod.ternary_loss_grad(im1, waux["im2_warped"], waux["mask_fw"], 3)
+    _, want_dfw = oracle_mod.image_warp_grad(gim2, im2, f_fw, want_im=False)
+    gim1 = oracle_mod.ternary_loss_grad(im2, waux["im1_warped"], waux["mask_bw"], 3)
+    _, want_dbw = oracle_mod.image_warp_grad(gim1, im1, f_bw, want_im=False)
+    for got_g, want_g in ((tfw.grad, want_dfw), (tbw.grad, want_dbw)):
+        np.testing.assert_allclose(got_g.cpu().numpy(), want_g, rtol=1e-3, atol=1e-4 * np.abs(want_g).max())
+
+
+def test_batch_shards_sum_to_whole_batch_cfg3(dev):
+    """The N-GPU partition on one device: compute_losses on contiguous batch shards with
+    norm_batch = global batch sums to the whole-batch losses, and each shard's flow gradients are
+    the corresponding slices of the whole-batch gradients (pairs are independent; only the
+    normalisation is global)."""
+    import bench
+    from unflow_amd import dist as udist
+    from unflow_amd import losses
+    B, world = 8, 3                                  # ragged: shards of 3, 3, 2 pairs
+    wl = bench.Workload(B, dev, seed=77, global_batch=B, features=False)
+    terms = ("ternary", "sym", "occ", "fb", "smooth_2nd")
+
+    def run(sl, norm_batch):
+        ffw = wl.flow_fw[sl].detach().clone().requires_grad_(True)
+        fbw = wl.flow_bw[sl].detach().clone().requires_grad_(True)
+        ls = losses.compute_losses(wl.im1[sl], wl.im2[sl], ffw, fbw, border_mask=wl.border[sl], mask_occlusion="fb",
+                                   data_max_distance=3, norm_batch=norm_batch, terms=terms)
+        (ls["ternary"] + 3.0 * ls["smooth_2nd"] + 0.2 * ls["fb"] + 12.4 * ls["occ"]).backward()
+        return {k: float(v) for k, v in ls.items()}, ffw.grad, fbw.grad
+    whole, g_fw, g_bw = run(slice(0, B), 0)
+    total = {k: 0.0 for k in terms}
+    for r in range(world):
+        s, e = udist.shard_range(B, r, world)
+        part, p_fw, p_bw = run(slice(s, e), B)
+        for k in terms:
+            total[k] += part[k]
+        for got, want in ((p_fw, g_fw[s:e]), (p_bw, g_bw[s:e])):
+            assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    for k in terms:
+        np.testing.assert_allclose(total[k], whole[k], rtol=1e-6, err_msg=k)

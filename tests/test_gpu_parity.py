@@ -683,3 +683,109 @@ def test_empty_inputs(dev):
     assert float(losses.smoothness_loss(torch.zeros((0, 4, 4, 2), device=dev))) == 0.0
     assert float(losses.gradient_loss(torch.zeros((0, 4, 4, 3), device=dev), torch.zeros((0, 4, 4, 3), device=dev),
                                       torch.zeros((0, 4, 4, 1), device=dev))) == 0.0
+
+
+# ----------------------------------------------------------------------------- round-2 additions
+@pytest.mark.parametrize("B,H,W,C,oh,ow", [(2, 5, 18, 3, 2, 9), (1, 7, 9, 1, 3, 4), (2, 25, 39, 3, 12, 19), (1, 3, 3, 2, 1, 1),
+                                           (1, 96, 320, 3, 24, 80), (1, 9, 31, 1, 4, 15)])
+def test_resize_area_vs_oracle(oracle_mod, dev, B, H, W, C, oh, ow):
+    """util.downsample's odd-extent branch (core/util.py:28, tf.image.resize_area; assumption A3,
+    PARITY UNPINNED by the reference).  Same operation order as the oracle: 1e-6."""
+    from unflow_amd import util
+    rng = np.random.default_rng(H * 10 + W)
+    x = rng.uniform(size=(B, H, W, C)).astype(np.float32)
+    got = util.resize_area(T(x, dev), (oh, ow))
+    assert got.shape == (B, oh, ow, C)
+    close(got, oracle_mod.resize_area(x, oh, ow), 1e-6, 1e-7)
+
+
+def test_util_downsample_dispatch_on_gpu(oracle_mod, dev):
+    from unflow_amd import ops, util
+    rng = np.random.default_rng(12)
+    even = rng.uniform(size=(2, 8, 12, 3)).astype(np.float32)
+    assert torch.equal(util.downsample(T(even, dev), 2), ops.downsample(T(even, dev), 2))
+    with pytest.raises(ValueError, match="divisible by scale"):
+        util.downsample(T(np.zeros((1, 6, 8, 1), np.float32), dev), 4)        # even, not divisible: reaches the op
+    odd = rng.uniform(size=(2, 5, 18, 3)).astype(np.float32)
+    close(util.downsample(T(odd, dev), 2), oracle_mod.util_downsample(odd, 2), 1e-6, 1e-7)
+    assert util.downsample(T(rng.uniform(size=(1, 9, 10, 1)).astype(np.float32), dev), 4).shape == (1, 2, 2, 1)
+    assert util.resize_area(torch.zeros((0, 5, 7, 3), device=dev), (2, 3)).shape == (0, 2, 3, 3)
+
+
+def test_pyramid_loss_odd_extents_vs_oracle(oracle_mod, dev):
+    """A resolution whose pyramid levels turn odd (200x312 -> 50x78 -> 25x39 -> 12x19 -> 6x9 -> 3x4):
+    levels below 25x39 go through resize_area on both sides."""
+    from unflow_amd import unsupervised
+    rng = np.random.default_rng(44)
+    B, H, W = 1, 200, 312
+    im1, im2, _ = _pair(rng, B, H, W)
+    border = oracle_mod.create_border_mask((B, H, W))
+    shapes = [(50, 78), (25, 39), (12, 19), (6, 9), (3, 4)]
+    fws = [(rng.standard_normal((B, h, w, 2)) * 0.3).astype(np.float32) for h, w in shapes]
+    bws = [(-f + rng.standard_normal(f.shape) * 0.05).astype(np.float32) for f in fws]
+    params = dict(pyramid_loss=True, mask_occlusion="fb", border_mask=True, ternary_weight=1.0, smooth_2nd_weight=3.0,
+                  fb_weight=0.2, occ_weight=12.4)
+    want, want_terms = oracle_mod.pyramid_loss(im1, im2, border, fws, bws, params)
+    tf_ = [T(f, dev).requires_grad_(True) for f in fws]
+    tb_ = [T(f, dev).requires_grad_(True) for f in bws]
+    got, got_terms = unsupervised.pyramid_loss(T(im1, dev), T(im2, dev), T(border, dev), tf_, tb_, params)
+    np.testing.assert_allclose(float(got.detach()), want, rtol=2e-4)       # small levels: see test_compute_losses_vs_oracle
+    for k in ("ternary", "smooth_2nd", "fb", "occ"):
+        np.testing.assert_allclose(float(got_terms[k]), want_terms[k], rtol=2e-4, err_msg=k)
+    got.backward()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in tf_ + tb_)
+
+
+def test_correlation_flip_rejects_a_volume_of_other_attrs(dev):
+    """A volume built with non-default attrs flipped with the defaults would be overrun (the
+    launch is sized from the attrs): the shape is checked on the host AND in the C entry point."""
+    import ctypes
+    from unflow_amd import _lib, ops
+    vol = torch.zeros((1, 81, 8, 8), device=dev)              # 9x9 displacements: max_displacement 8, stride_2 2
+    with pytest.raises(ValueError, match="attrs imply"):
+        ops.correlation_flip(vol)
+    assert ops.correlation_flip(vol, max_displacement=8, pad=8).shape == vol.shape
+    out = torch.empty_like(vol)
+    rc = _lib.load().unflow_correlation_flip(ctypes.c_void_p(vol.data_ptr()), None, ctypes.c_void_p(out.data_ptr()),
+                                             1, 81, 8, 8, 1, 20, 20, 1, 2, None)
+    assert rc == _lib.UNFLOW_ERR_INVALID_ARGUMENT and "441" in _lib.last_error()
+
+
+def test_ternary_warped_gives_the_composed_set_of_gradients(dev):
+    """Which gradients exist must not depend on whether compute_losses takes the fused census path:
+    an im2 that requires grad gets one (through image_warp) on both paths; im1 never does."""
+    from unflow_amd import losses
+    from unflow_amd.image_warp import image_warp
+    rng = np.random.default_rng(73)
+    B, H, W = 1, 48, 64
+    im1, im2, flow = _pair(rng, B, H, W)
+    mask = torch.ones((B, H, W, 1), device=dev)
+    grads = []
+    for fused_entry in (True, False):
+        a, b = T(im1, dev).requires_grad_(True), T(im2, dev).requires_grad_(True)
+        f = T(flow, dev).requires_grad_(True)
+        if fused_entry:
+            loss = losses.ternary_loss_warped(a, b, f, mask, max_distance=3)
+        else:
+            loss = losses.ternary_loss(a, image_warp(b, f), mask, max_distance=3)
+        loss.backward()
+        assert a.grad is None and b.grad is not None and f.grad is not None
+        grads.append((b.grad, f.grad))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    # without a gradient request on im2 the fused kernels run and agree with the composition
+    f1 = T(flow, dev).requires_grad_(True)
+    l1 = losses.ternary_loss_warped(T(im1, dev), T(im2, dev), f1, mask, max_distance=3)
+    l1.backward()
+    assert float(l1) == float(loss.detach())
+    close(f1.grad, N(grads[1][1]), 1e-5, 1e-6 * float(grads[1][1].abs().max()))
+
+
+def test_stream_copy_probe(dev):
+    import ctypes
+    from unflow_amd import _lib
+    a = torch.randn(1 << 20, device=dev)
+    b = torch.zeros_like(a)
+    _lib.check(_lib.load().unflow_stream_copy(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()),
+                                              ctypes.c_size_t(a.numel() * 4 - 16), None))
+    torch.cuda.synchronize()
+    assert torch.equal(a[:-4], b[:-4]) and float(b[-4:].abs().max()) == 0.0

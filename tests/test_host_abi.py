@@ -97,7 +97,9 @@ def test_product_package_never_imports_the_oracle():
 
 def test_downsample_dispatcher_mirrors_reference():
     from unflow_amd import util
-    with pytest.raises(NotImplementedError):
-        util.downsample(torch.zeros(1, 5, 4, 1), 2)     # odd extent: reference uses resize_area
+    with pytest.raises(RuntimeError, match="no CPU kernels"):
+        util.downsample(torch.zeros(1, 5, 4, 1), 2)     # odd extent: resize_area (util.py:28), also HIP only
+    with pytest.raises(ValueError, match="must be positive"):
+        util.resize_area(torch.zeros(1, 5, 4, 1), (0, 2))
     with pytest.raises(RuntimeError, match="no CPU kernels"):
         util.downsample(torch.zeros(1, 4, 4, 1), 2)     # even extent reaches the op

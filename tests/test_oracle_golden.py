@@ -249,3 +249,32 @@ def test_seeded_fixture_is_reproducible(seeded, oracle_mod):
     np.testing.assert_array_equal(oracle_mod.census_transform(seeded["im1"], 3, 0.9), seeded["census_sig1"])
     np.testing.assert_array_equal(oracle_mod.stacked_inputs(seeded["im1"], seeded["im2"], seeded["stacked_flow_lr"]),
                                   seeded["stacked_inputs"])
+
+
+# ----------------------------------------------------------------------------- resize_area (util.downsample, odd extents)
+@pytest.mark.parametrize("H,W,oh,ow", [(5, 18, 2, 9), (7, 9, 3, 4), (12, 40, 3, 10), (3, 3, 1, 1), (9, 31, 4, 15), (5, 5, 5, 5)])
+def test_resize_area_vs_overlap_integral(oracle_mod, H, W, oh, ow):
+    """PARITY UNPINNED (tf.image.resize_area is third-party, assumption A3): the C restatement of
+    TF's loop against an independent float64 overlap integral; on divisible extents it is the
+    Downsample op's box mean (ops/downsample_op.cu.cc:38-46); a constant image stays constant."""
+    rng = np.random.default_rng(H * 100 + W)
+    x = rng.uniform(size=(2, H, W, 3)).astype(np.float32)
+    got = oracle_mod.resize_area(x, oh, ow)
+    assert got.shape == (2, oh, ow, 3)
+    np.testing.assert_allclose(got, np_ref.resize_area(x, oh, ow), rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(oracle_mod.resize_area(np.full((1, H, W, 1), 0.75, np.float32), oh, ow), 0.75, rtol=1e-6)
+    if H % oh == 0 and W % ow == 0 and H // oh == W // ow:
+        np.testing.assert_allclose(got, oracle_mod.downsample(x, H // oh), rtol=1e-6, atol=1e-7)
+
+
+def test_util_downsample_dispatch(oracle_mod):
+    """core/util.py:23-28: even extents -> the op (which raises when they do not divide by num),
+    an odd extent -> resize_area to (int(H/num), int(W/num))."""
+    rng = np.random.default_rng(8)
+    x = rng.uniform(size=(1, 8, 12, 2)).astype(np.float32)
+    np.testing.assert_array_equal(oracle_mod.util_downsample(x, 2), oracle_mod.downsample(x, 2))
+    with pytest.raises(ValueError, match="divisible by scale"):
+        oracle_mod.util_downsample(np.zeros((1, 6, 8, 1), np.float32), 4)
+    y = rng.uniform(size=(1, 5, 18, 2)).astype(np.float32)
+    np.testing.assert_array_equal(oracle_mod.util_downsample(y, 2), oracle_mod.resize_area(y, 2, 9))
+    assert oracle_mod.util_downsample(rng.uniform(size=(1, 9, 10, 1)).astype(np.float32), 4).shape == (1, 2, 2, 1)

@@ -10,6 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunflow_hip.so")
 
+ABI_VERSION = 2      # UNFLOW_ABI_VERSION of include/unflow_hip.h
 UNFLOW_OK = 0
 UNFLOW_ERR_INVALID_ARGUMENT = 1
 UNFLOW_ERR_LAUNCH = 2
@@ -24,6 +25,7 @@ _LL = ctypes.c_longlong
 SIGNATURES = {
     "unflow_abi_version": (_I, []),
     "unflow_last_error": (ctypes.c_char_p, []),
+    "unflow_stream_copy": (_I, [_P, _P, ctypes.c_size_t, _P]),
     "unflow_correlation_geometry": (_I, [_I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]),
     "unflow_correlation_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -34,7 +36,7 @@ SIGNATURES = {
     "unflow_forward_warp_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "unflow_forward_warp_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "unflow_downsample_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
-    "unflow_reduce_workspace_floats": (ctypes.c_size_t, [_LL]),
+    "unflow_reduce_workspace_floats": (ctypes.c_size_t, [_I, _I, _I]),
     "unflow_ternary_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),
     "unflow_ternary_loss_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "unflow_ternary_loss_warp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),
@@ -52,7 +54,7 @@ SIGNATURES = {
     "unflow_gradient_loss_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _LL, _P]),
     "unflow_gradient_loss_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _LL, _P]),
     "unflow_gradient_delta": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "unflow_correlation_flip": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "unflow_correlation_flip": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_fwd_f16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_bwd_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_census_transform": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
@@ -60,6 +62,7 @@ SIGNATURES = {
     "unflow_stacked_inputs_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "unflow_resize_bilinear_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "unflow_resize_bilinear_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "unflow_resize_area_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None
@@ -85,7 +88,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.unflow_abi_version() != 1:
+        if lib.unflow_abi_version() != ABI_VERSION:
             raise UnflowLibraryError("libunflow_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -768,10 +768,13 @@ int reduce_partials(const float *partial, int n, double inv_norm, float *loss, h
 
 using namespace unflow;
 
-extern "C" size_t unflow_reduce_workspace_floats(long long n_pixels) {
-  // >= number of 32x8 tiles of any [B,H,W] with B*H*W == n_pixels (each tile
-  // holds at least one pixel) and >= kReduceBlocks for the 1-D reductions.
-  return (size_t)(n_pixels > kReduceBlocks ? n_pixels : kReduceBlocks);
+extern "C" size_t unflow_reduce_workspace_floats(int B, int H, int W) {
+  // One partial per workgroup: the 32x8 tiles of the tiled loss kernels (census, stencils)
+  // are the finest grid (the pair-symmetric census uses 58..60 x 64 pixel workgroups, the
+  // 1-D reductions kReduceBlocks blocks).
+  if (B <= 0 || H <= 0 || W <= 0) return (size_t)kReduceBlocks;
+  const long long tiles = tile_blocks(B, H, W);
+  return (size_t)(tiles > kReduceBlocks ? tiles : kReduceBlocks);
 }
 
 extern "C" int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped, const float *mask, float *loss,

@@ -312,11 +312,14 @@ __global__ __launch_bounds__(256) void corr_flip_kernel(const float *__restrict_
 }  // namespace
 }  // namespace unflow
 
-extern "C" int unflow_correlation_flip(const float *in, const float *add, float *out, int B, int H, int W,
+extern "C" int unflow_correlation_flip(const float *in, const float *add, float *out, int B, int D, int H, int W,
                                        int kernel_size, int max_displacement, int pad, int stride_1, int stride_2,
                                        unflow_stream_t stream) {
   CorrGeometry g;
   if (int rc = corr_geometry_init(&g, H, W, kernel_size, max_displacement, pad, stride_1, stride_2)) return rc;
+  if (D != g.out_channels)   // the launch is sized from the attrs: a volume built with other attrs would be overrun
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation_flip: volume has %d displacement planes, the attrs imply %d", D,
+                g.out_channels);
   if (kernel_size != 1 || stride_1 != 1 || pad != max_displacement || g.out_height != H || g.out_width != W)
     return fail(UNFLOW_ERR_INVALID_ARGUMENT,
                 "correlation_flip needs kernel_size 1, stride_1 1 and pad == max_displacement (output grid == input grid)");

@@ -29,6 +29,7 @@
 #include "common.h"
 #include "correlation.h"
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
       const float *src = ob + (r * RW + c4 * 4) * (SLAB_DY * GW) + ddl * GW + dxx;
       const float4 v = make_float4(src[0], src[SLAB_DY * GW], src[2 * SLAB_DY * GW], src[3 * SLAB_DY * GW]);
       float *dst = out + (item * D + d) * plane + (long long)y * W + x;
-      if (x + 3 < W && (W & 3) == 0) {
+      if (VEC == 4 && x + 3 < W && (W & 3) == 0) {   // VEC == 4: the host checked 16-byte alignment of out
         *reinterpret_cast<float4 *>(dst) = v;
       } else {
         dst[0] = v.x;
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
         auto *dst = gout + (item * C + c) * plane + (long long)y * W + x;
         if constexpr (F16) {   // W % 4 == 0 and 8-byte aligned tensors are preconditions of this variant
           *reinterpret_cast<f16x4 *>(dst) = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        } else if (x + 3 < W && (W & 3) == 0) {
+        } else if (VA == 4 && x + 3 < W && (W & 3) == 0) {   // VA == 4: the host checked 16-byte alignment of gout
           *reinterpret_cast<float4 *>(dst) = v;
         } else {
           dst[0] = v.x;
@@ -1016,14 +1017,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// > 64 KiB of dynamic LDS needs an opt-in, once per kernel.  The kernel is a
-// template VALUE parameter: all instantiations of one kernel template share a
-// function type, and a static keyed on the type would be set for the first only.
+// > 64 KiB of dynamic LDS needs an opt-in, per kernel AND per device (the attribute is set on
+// the current device's copy of the function).  The kernel is a template VALUE parameter: all
+// instantiations of one kernel template share a function type, and a flag keyed on the type
+// would be set for the first only.  A failure is returned, never remembered.
+constexpr int kMaxDevices = 64;
 template <auto KERNEL>
 int reserve_lds(size_t smem, const char *what) {
-  static const hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  static std::atomic<bool> granted[kMaxDevices];      // zero-initialised
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return launch_status(what);
+  const bool tracked = dev >= 0 && dev < kMaxDevices;
+  if (tracked && granted[dev].load(std::memory_order_acquire)) return UNFLOW_OK;
+  const hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (st != hipSuccess) return fail(UNFLOW_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS (%s)", what, smem, hipGetErrorString(st));
+  if (tracked) granted[dev].store(true, std::memory_order_release);
   return UNFLOW_OK;
 }
 
@@ -1047,7 +1056,7 @@ int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, 
   const dim3 grid(nbx * nby * B * S);
   const size_t smem = sizeof(float) * 2 * STAGE;
   // 16-byte DMA segments need 16-byte aligned rows
-  const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1);
+  const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(out);   // out is stored as float4
   if (wide) {   // two half-window workgroups per region, two workgroups per CU: 0.76 -> 0.66 ms at B=32
     const size_t smem2 = sizeof(float) * 2 * STAGEH;
     if (int rc = reserve_lds<corr_mfma_fwd_half_kernel<4, false>>(smem2, "correlation_fwd (mfma, half windows)")) return rc;
@@ -1085,7 +1094,7 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
   // one workgroup per (pair, row class, channel group, column strip); one launch per gradient
   const dim3 grid(nbx * nch * S * B);
   const size_t smem = sizeof(float) * SW_LDS;
-  const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(topdiff);
+  const bool wide = (W % 4) == 0 && aligned16(in0) && aligned16(in1) && aligned16(topdiff) && aligned16(g0) && aligned16(g1);
 #define UNFLOW_LAUNCH(VA, VT0, FULL)                                                                               \
   do {                                                                                                              \
     if (int rc = reserve_lds<corr_mfma_bwd_kernel<VA, VT0, false, FULL>>(smem, "correlation_bwd (mfma)")) return rc; \

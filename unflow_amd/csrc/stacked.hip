@@ -156,6 +156,46 @@ __global__ __launch_bounds__(kBlock) void stacked_inputs_kernel(const float *__r
   }
 }
 
+// tf.image.resize_area (TensorFlow 1.x, align_corners=False; third-party, its published
+// algorithm, assumption A3): output pixel (y, x) is the box [y*sy, (y+1)*sy) x [x*sx, (x+1)*sx)
+// of the input averaged with fractional coverage weights; scale = in / out in float, the
+// box rows i = floor(in_y) .. ceil(in_y1)-1 weigh  i < in_y ? (i+1 > in_y1 ? sy : i+1-in_y)
+// : (i+1 > in_y1 ? in_y1-i : 1), indices clamped to the image; each row is summed over x
+// first, rows are then combined, the result is multiplied by 1/(sy*sx).  One lane per output
+// element; the dispatcher only sends odd-extent pyramid levels here (core/util.py:23-28).
+__device__ inline float area_weight(int i, float lo, float hi, float scale) {
+  return (float)i < lo ? ((float)(i + 1) > hi ? scale : (float)(i + 1) - lo) : ((float)(i + 1) > hi ? hi - (float)i : 1.0f);
+}
+
+__global__ __launch_bounds__(kBlock) void resize_area_fwd_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                                 int H, int W, int C, int oh, int ow, float sy,
+                                                                 float sx, long long total) {
+  const float norm = 1.0f / (sy * sx);
+  for (long long idx = blockIdx.x * (long long)kBlock + threadIdx.x; idx < total; idx += (long long)gridDim.x * kBlock) {
+    const int c = (int)(idx % C);
+    long long r = idx / C;
+    const int x = (int)(r % ow);
+    r /= ow;
+    const int y = (int)(r % oh);
+    const long long b = r / oh;
+    const float in_y = (float)y * sy, in_y1 = (float)(y + 1) * sy;
+    const float in_x = (float)x * sx, in_x1 = (float)(x + 1) * sx;
+    const int y0 = (int)floorf(in_y), y1 = (int)ceilf(in_y1);
+    const int x0 = (int)floorf(in_x), x1 = (int)ceilf(in_x1);
+    float sum = 0.f;
+    for (int i = y0; i < y1; ++i) {
+      const float *row = in + ((b * H + min(max(i, 0), H - 1)) * (long long)W) * C + c;
+      float sum_y = mul_rn(row[(long long)min(max(x0, 0), W - 1) * C], area_weight(x0, in_x, in_x1, sx));
+      if (x0 + 1 != x1) {
+        for (int j = x0 + 1; j < x1 - 1; ++j) sum_y = add_rn(sum_y, row[(long long)min(max(j, 0), W - 1) * C]);
+        sum_y = add_rn(sum_y, mul_rn(row[(long long)min(max(x1 - 1, 0), W - 1) * C], area_weight(x1 - 1, in_x, in_x1, sx)));
+      }
+      sum = add_rn(sum, mul_rn(sum_y, area_weight(i, in_y, in_y1, sy)));
+    }
+    out[idx] = mul_rn(sum, norm);
+  }
+}
+
 inline unsigned grid_for(long long total) {
   const long long g = (total + kBlock - 1) / kBlock;
   return (unsigned)(g < 1 ? 1 : (g > 65535LL * 16 ? 65535LL * 16 : g));
@@ -188,6 +228,17 @@ extern "C" int unflow_resize_bilinear_fwd(const float *in, float *out, int B, in
     hipLaunchKernelGGL(resize_bilinear_fwd_kernel<0>, dim3(grid_for(total)), dim3(kBlock), 0, s, in, out, h, w, H, W, C,
                        sh, sw, mult, total);
   return launch_status("resize_bilinear_fwd");
+}
+
+extern "C" int unflow_resize_area_fwd(const float *in, float *out, int B, int H, int W, int C, int out_h, int out_w,
+                                      unflow_stream_t stream) {
+  if (int rc = check_resize("resize_area", B, H, W, out_h, out_w, C)) return rc;
+  const long long total = (long long)B * out_h * out_w * C;
+  if (total == 0) return UNFLOW_OK;
+  const float sy = (float)H / (float)out_h, sx = (float)W / (float)out_w;
+  hipLaunchKernelGGL(resize_area_fwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), in, out, H, W, C,
+                     out_h, out_w, sy, sx, total);
+  return launch_status("resize_area_fwd");
 }
 
 extern "C" int unflow_resize_bilinear_bwd(const float *gout, float *gin, int B, int h, int w, int H, int W, int C,

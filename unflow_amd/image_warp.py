@@ -49,12 +49,8 @@ class _ImageWarp(torch.autograd.Function):
 
 
 def image_warp(im, flow):
-    """Performs a backward warp of an image using the predicted flow.
-
-    Args:
-        im: Batch of images. [num_batch, height, width, channels]
-        flow: Batch of flow vectors. [num_batch, height, width, 2]
-    Returns:
-        warped: transformed image of the same shape as the input image.
-    """
+    """Mirror of ``image_warp`` (src/e2eflow/core/image_warp.py:4-76): samples ``im``
+    [B,H,W,C] bilinearly at ``(x + flow[...,0], y + flow[...,1])`` with the tap indices
+    clamped to the image (``floor`` is taken of the flow, as the reference does); returns
+    a tensor shaped like ``im``.  Differentiable in both arguments."""
     return _ImageWarp.apply(im, flow)

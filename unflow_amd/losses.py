@@ -21,8 +21,9 @@ from .ops import _check_flow, _dev, _ptr, _require_rank4, _stream, forward_warp
 DISOCC_THRESH = 0.8  # losses.py:9
 
 
-def _workspace(n_pixels, device):
-    n = _lib.load().unflow_reduce_workspace_floats(int(n_pixels))
+def _workspace(B, H, W, device):
+    """Per-workgroup partial sums of one loss call (a few thousand floats)."""
+    n = _lib.load().unflow_reduce_workspace_floats(int(B), int(H), int(W))
     return torch.empty(int(n), device=device, dtype=torch.float32)
 
 
@@ -121,7 +122,7 @@ def sym_loss(mask, density_other, norm_count=0):
     if C != 1 or density_other.shape != mask.shape:
         raise ValueError("sym_loss expects two [B,H,W,1] maps")
     loss = torch.empty((), device=mask.device, dtype=torch.float32)
-    ws = _workspace(B * H * W, mask.device)
+    ws = _workspace(B, H, W, mask.device)
     with torch.cuda.device(mask.device):
         _lib.check(_lib.load().unflow_sym_loss_fwd(_ptr(mask), _ptr(density_other), DISOCC_THRESH, _ptr(loss),
                                                    _ptr(ws), B, H, W, norm_count, _stream()))
@@ -142,7 +143,7 @@ class _Charbonnier(torch.autograd.Function):
             if mask.shape[:3] != x.shape[:3] or mc not in (1, C):
                 raise ValueError("mask channels must be 1 or match x")
         loss = torch.empty((), device=x.device, dtype=torch.float32)
-        ws = _workspace(B * H * W, x.device)
+        ws = _workspace(B, H, W, x.device)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().unflow_charbonnier_fwd(
                 _ptr(x), _ptr(mask), mc, _ptr(loss), _ptr(ws), B, H, W, C, alpha, beta, epsilon,
@@ -210,7 +211,7 @@ class _SmoothnessLoss(torch.autograd.Function):
         _check_flow(None, flow)
         B, H, W, _ = flow.shape
         loss = torch.empty((), device=flow.device, dtype=torch.float32)
-        ws = _workspace(B * H * W, flow.device)
+        ws = _workspace(B, H, W, flow.device)
         with torch.cuda.device(flow.device):
             _lib.check(_lib.load().unflow_smoothness_loss_fwd(_ptr(flow), _ptr(loss), _ptr(ws), B, H, W,
                                                               order, norm_count, _stream()))
@@ -268,7 +269,7 @@ class _GradientLoss(torch.autograd.Function):
         if tuple(mask.shape) != (B, H, W, 1):
             raise ValueError("mask must have shape %s, got %s" % ((B, H, W, 1), tuple(mask.shape)))
         loss = torch.empty((), device=im1.device, dtype=torch.float32)
-        ws = _workspace(B * H * W, im1.device)
+        ws = _workspace(B, H, W, im1.device)
         with torch.cuda.device(im1.device):
             _lib.check(_lib.load().unflow_gradient_loss_fwd(_ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss),
                                                             _ptr(ws), B, H, W, norm_count, _stream()))
@@ -309,7 +310,7 @@ class _TernaryLoss(torch.autograd.Function):
             raise ValueError("mask must have shape %s, got %s" % ((B, H, W, 1), tuple(mask.shape)))
         loss = torch.empty((), device=im1.device, dtype=torch.float32)
         dldd = torch.empty((B, H, W), device=im1.device, dtype=torch.float32)
-        ws = _workspace(B * H * W, im1.device)
+        ws = _workspace(B, H, W, im1.device)
         with torch.cuda.device(im1.device):
             _lib.check(_lib.load().unflow_ternary_loss_fwd(
                 _ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss), _ptr(dldd), _ptr(None), _ptr(ws),
@@ -346,7 +347,7 @@ class _TernaryWarped(torch.autograd.Function):
             raise ValueError("ternary_loss_warped expects [B,H,W,3] images and a [B,H,W,1] mask")
         loss = torch.empty((), device=im1.device, dtype=torch.float32)
         dldd, gray1, gray2w = (torch.empty((B, H, W), device=im1.device, dtype=torch.float32) for _ in range(3))
-        ws = _workspace(B * H * W, im1.device)
+        ws = _workspace(B, H, W, im1.device)
         with torch.cuda.device(im1.device):
             _lib.check(_lib.load().unflow_ternary_loss_warp_fwd(
                 _ptr(im1), _ptr(im2), _ptr(flow_d), _ptr(mask), _ptr(loss), _ptr(dldd), _ptr(gray1), _ptr(gray2w),
@@ -372,8 +373,12 @@ def ternary_loss_warped(im1, im2, flow, mask, max_distance=1, norm_count=0):
     """``ternary_loss(im1, image_warp(im2, flow), mask, max_distance)`` (losses.py:22,82-83) whose
     forward evaluates the warp while staging the census tiles and whose backward goes straight
     to ``flow`` (max_distance 2 and 3): two kernels instead of four, and neither the warped
-    image nor its [B,H,W,3] gradient touches HBM.  Other radii compose the two ops."""
-    if max_distance in (2, 3) and im1.numel() // 3 < (1 << 29):
+    image nor its [B,H,W,3] gradient touches HBM.  Other radii compose the two ops, and so
+    does an ``im2`` that requires a gradient: the fused backward only differentiates down to
+    ``flow``, the composed one also reaches ``im2`` through ``image_warp`` (``im1`` gets none
+    on either path: ``ternary_loss`` treats it as a constant, core/augment.py:53,108)."""
+    fused = max_distance in (2, 3) and im1.numel() // 3 < (1 << 29)
+    if fused and not (torch.is_grad_enabled() and im2.requires_grad):
         return _TernaryWarped.apply(im1, im2, flow, mask, max_distance, norm_count)
     return ternary_loss(im1, image_warp(im2, flow), mask, max_distance, norm_count)
 
@@ -391,7 +396,7 @@ def ternary_dist(im1, im2_warped, max_distance=1):
     mask = torch.ones((B, H, W, 1), device=im1.device, dtype=torch.float32)
     loss = torch.empty((), device=im1.device, dtype=torch.float32)
     dist = torch.empty((B, H, W, 1), device=im1.device, dtype=torch.float32)
-    ws = _workspace(B * H * W, im1.device)
+    ws = _workspace(B, H, W, im1.device)
     with torch.cuda.device(im1.device):
         _lib.check(_lib.load().unflow_ternary_loss_fwd(
             _ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss), _ptr(None), _ptr(dist), _ptr(ws), B,

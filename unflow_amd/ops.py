@@ -228,9 +228,12 @@ def correlation_flip(volume, add=None, kernel_size=1, max_displacement=20, pad=2
         if add.shape != volume.shape:
             raise ValueError("add must have the shape of volume")
     B, D, H, W = volume.shape
+    want = correlation_output_shape((B, 1, H, W), kernel_size, max_displacement, pad, stride_1, stride_2)["correlation"]
+    if (D, H, W) != tuple(want[1:]):
+        raise ValueError("volume has shape %s, the attrs imply [B,%d,%d,%d]" % ((tuple(volume.shape),) + tuple(want[1:])))
     out = torch.empty_like(volume)
     with torch.cuda.device(volume.device):
-        _lib.check(_lib.load().unflow_correlation_flip(_ptr(volume), _ptr(add), _ptr(out), B, H, W, kernel_size,
+        _lib.check(_lib.load().unflow_correlation_flip(_ptr(volume), _ptr(add), _ptr(out), B, D, H, W, kernel_size,
                                                        max_displacement, pad, stride_1, stride_2, _stream()))
     return out
 
