@@ -185,7 +185,7 @@ def test_bench_loss_leg_cfg3(oracle_mod, dev):
     census kernels and the warp-fused occlusion kernel, forward and backward to both flows.
     (i) against the composed HIP path (image_warp -> fb_occlusion -> ternary_loss / forward_warp ->
     charbonnier) on the whole batch: loss 1e-6, flow gradients 1e-5 of their scale;
-    (ii) one pair against the CPU oracle at the tolerances of test_compute_losses_vs_oracle."""
+    (ii) one pair against the CPU oracle: scalars 1e-5, flow gradients 1e-5 of their scale."""
     import bench
     from unflow_amd import losses
     from unflow_amd.image_warp import image_warp
@@ -193,7 +193,7 @@ def test_bench_loss_leg_cfg3(oracle_mod, dev):
     B = 32
     wl = bench.Workload(B, dev, seed=1234, global_batch=B, features=False)
     ls = wl.loss_leg()
-    fused = float(ls["ternary"])
+    fused = float(ls["ternary"].detach())
     g_fw, g_bw = wl.flow_fw.grad.clone(), wl.flow_bw.grad.clone()
     assert np.isfinite(fused) and torch.isfinite(g_fw).all() and torch.isfinite(g_bw).all()
 
@@ -236,7 +236,7 @@ def test_bench_loss_leg_cfg3(oracle_mod, dev):
     gim1 = oracle_mod.ternary_loss_grad(im2, waux["im1_warped"], waux["mask_bw"], 3)
     _, want_dbw = oracle_mod.image_warp_grad(gim1, im1, f_bw, want_im=False)
     for got_g, want_g in ((tfw.grad, want_dfw), (tbw.grad, want_dbw)):
-        np.testing.assert_allclose(got_g.cpu().numpy(), want_g, rtol=1e-3, atol=1e-4 * np.abs(want_g).max())
+        np.testing.assert_allclose(got_g.cpu().numpy(), want_g, rtol=1e-5, atol=1e-5 * np.abs(want_g).max())
 
 
 def test_batch_shards_sum_to_whole_batch_cfg3(dev):

@@ -97,7 +97,7 @@ def test_seeded_warps(seeded, dev):
     close(d_im, seeded["image_warp_dim"], 1e-5, 1e-5)
     close(d_flow, seeded["image_warp_dflow"], 1e-5, 1e-5)
     close(ops.forward_warp(flow), seeded["forward_warp"], 1e-5, 1e-5)
-    close(ops.forward_warp_grad(T(seeded["forward_warp_gin"], dev), flow), seeded["forward_warp_grad"], 1e-4, 1e-5)
+    close(ops.forward_warp_grad(T(seeded["forward_warp_gin"], dev), flow), seeded["forward_warp_grad"], 1e-5, 1e-5)
     close(ops.downsample(T(seeded["im1"], dev), 2), seeded["downsample2"], 1e-6, 1e-6)
     close(ops.downsample(T(seeded["im1"], dev), 4), seeded["downsample4"], 1e-6, 1e-6)
 
@@ -112,7 +112,7 @@ def test_seeded_census(seeded, dev, r):
     np.testing.assert_allclose(float(loss.detach()), float(seeded["ternary_loss_r%d" % r]), rtol=1e-5)
     loss.backward()
     want = seeded["ternary_grad_r%d" % r]
-    close(im2w.grad, want, 1e-4, 1e-4 * np.abs(want).max())  # gradients: reference checks at 1e-3
+    close(im2w.grad, want, 1e-5, 1e-5 * np.abs(want).max())  # 1e-5 of the gradient's scale (the reference's own checks use 1e-3)
 
 
 def test_smoothness_deltas_known_answer(kat, dev):
@@ -144,13 +144,13 @@ def test_seeded_stencil_terms(seeded, dev):
         np.testing.assert_allclose(float(loss.detach()), float(seeded["smooth_loss_o%d" % order]), rtol=1e-5)
         loss.backward()
         want = seeded["smooth_grad_o%d" % order]
-        close(flow.grad, want, 1e-4, 1e-5 * np.abs(want).max())
+        close(flow.grad, want, 1e-5, 1e-5 * np.abs(want).max())
     im1, im2w = T(seeded["im1"], dev), T(seeded["image_warp"], dev).requires_grad_(True)
     loss = losses.gradient_loss(im1, im2w, T(seeded["border_mask"], dev))
     np.testing.assert_allclose(float(loss.detach()), float(seeded["gradient_loss"]), rtol=1e-5)
     loss.backward()
     want = seeded["gradient_loss_grad"]
-    close(im2w.grad, want, 1e-4, 1e-5 * np.abs(want).max())
+    close(im2w.grad, want, 1e-5, 1e-5 * np.abs(want).max())
 
 
 def test_seeded_extensions(seeded, dev):
@@ -174,6 +174,14 @@ def test_seeded_extensions(seeded, dev):
     ((2, 32, 16, 24), dict()),                                   # FlowNetC attrs
     ((1, 256, 16, 16), dict()),                                  # BASELINE cfg1 feature shape
     ((1, 7, 9, 13), dict()),                                     # ragged extents and channels
+    # C % 128 == 0 and W % 4 == 0: the persistent row-sweep backward (corr_mfma_bwd2_kernel) --
+    # odd heights (the two row classes differ in length), one-row classes, strips that leave the
+    # image, more tiles than the accumulator ring holds, item counts that do not divide by 8
+    ((1, 128, 9, 12), dict()),
+    ((3, 128, 7, 8), dict()),
+    ((1, 128, 2, 4), dict()),
+    ((1, 256, 100, 36), dict()),
+    ((2, 128, 30, 20), dict()),
     ((2, 6, 10, 12), dict(kernel_size=3, max_displacement=4, pad=3, stride_1=2, stride_2=2)),
     ((1, 5, 9, 11), dict(kernel_size=1, max_displacement=5, pad=2, stride_1=1, stride_2=2)),
     ((1, 4, 12, 9), dict(kernel_size=5, max_displacement=3, pad=6, stride_1=3, stride_2=1)),
@@ -342,7 +350,7 @@ def test_forward_warp_vs_oracle(oracle_mod, dev, B, H, W):
     close(got, want, 1e-5, 1e-5 * max(1.0, want.max()))
     g = rng.standard_normal(want.shape).astype(np.float32)
     got.backward(T(g, dev))
-    close(f.grad, oracle_mod.forward_warp_grad(g, flow), 1e-4, 1e-5)
+    close(f.grad, oracle_mod.forward_warp_grad(g, flow), 1e-5, 1e-5)
 
 
 def test_forward_warp_zero_flow_analytic(dev):
@@ -374,7 +382,7 @@ def test_census_vs_oracle(oracle_mod, dev, B, H, W, r):
     np.testing.assert_allclose(float(loss), want_loss, rtol=1e-5)
     (loss * 2.5).backward()
     want_grad = oracle_mod.ternary_loss_grad(im1, im2, mask, r, gout=2.5)
-    close(x.grad, want_grad, 1e-4, 1e-4 * np.abs(want_grad).max())
+    close(x.grad, want_grad, 1e-5, 1e-5 * np.abs(want_grad).max())      # measured 4e-7 of the scale
 
 
 def test_census_backward_ignores_memory_past_its_buffers(oracle_mod, dev):
@@ -391,7 +399,7 @@ def test_census_backward_ignores_memory_past_its_buffers(oracle_mod, dev):
         del poison                                                       # ... back to the caching allocator
         x = T(im2, dev).requires_grad_(True)
         losses.ternary_loss(T(im1, dev), x, T(mask, dev), max_distance=3).backward()
-        close(x.grad, want, 1e-4, 1e-4 * np.abs(want).max())
+        close(x.grad, want, 1e-5, 1e-5 * np.abs(want).max())
 
 
 def test_charbonnier_and_masks_vs_oracle(oracle_mod, dev):
@@ -407,7 +415,7 @@ def test_charbonnier_and_masks_vs_oracle(oracle_mod, dev):
             np.testing.assert_allclose(float(loss), oracle_mod.charbonnier_loss(x, mask, beta=beta), rtol=1e-5)
             loss.backward()
             want = oracle_mod.charbonnier_loss_grad(x, mask, beta=beta)
-            close(xt.grad, want, 1e-4, 1e-6 * max(1.0, np.abs(want).max()))
+            close(xt.grad, want, 1e-5, 1e-6 * max(1.0, np.abs(want).max()))
     z = torch.zeros((2, 5, 7, 1), device=dev)
     np.testing.assert_array_equal(N(losses.create_mask(z, [[1, 2], [0, 3]])), oracle_mod.create_mask((2, 5, 7), [[1, 2], [0, 3]]))
     big = torch.zeros((1, 384, 1280, 1), device=dev)
@@ -422,7 +430,7 @@ def test_charbonnier_and_masks_vs_oracle(oracle_mod, dev):
 
 @pytest.mark.parametrize("B,H,W", [(2, 40, 56), (1, 9, 33), (3, 8, 32), (1, 1, 1), (1, 2, 70), (2, 17, 3)])
 def test_stencil_terms_vs_oracle(oracle_mod, dev, B, H, W):
-    """smoothness / second-order / gradient loss, deltas bit-exact, losses 1e-5, gradients 1e-4
+    """smoothness / second-order / gradient loss, deltas bit-exact, losses 1e-5, gradients 1e-5 of their scale
     (tile 32x8: sizes below, at and across tile borders; degenerate 1x1)."""
     from unflow_amd import losses
     rng = np.random.default_rng(100 + H * W)
@@ -439,7 +447,7 @@ def test_stencil_terms_vs_oracle(oracle_mod, dev, B, H, W):
         np.testing.assert_allclose(float(loss.detach()), oracle_mod.smoothness_loss(flow, order), rtol=1e-5)
         (loss * 3.0).backward()
         wg = oracle_mod.smoothness_loss_grad(flow, order, gout=3.0)
-        close(f.grad, wg, 1e-4, 1e-5 * max(np.abs(wg).max(), 1e-30))
+        close(f.grad, wg, 1e-5, 1e-5 * max(np.abs(wg).max(), 1e-30))
         # a shard normalises by the global count
         np.testing.assert_allclose(float(lfn(T(flow, dev), norm_count=7 * B * H * W)),
                                    oracle_mod.smoothness_loss(flow, order, norm_count=7 * B * H * W), rtol=1e-5)
@@ -453,7 +461,7 @@ def test_stencil_terms_vs_oracle(oracle_mod, dev, B, H, W):
     np.testing.assert_allclose(float(loss.detach()), oracle_mod.gradient_loss(im1, im2, mask), rtol=1e-5)
     loss.backward()
     wg = oracle_mod.gradient_loss_grad(im1, im2, mask)
-    close(x.grad, wg, 1e-4, 1e-5 * max(np.abs(wg).max(), 1e-30))
+    close(x.grad, wg, 1e-5, 1e-5 * max(np.abs(wg).max(), 1e-30))
 
 
 @pytest.mark.parametrize("mask_occlusion,use_border", [("fb", True), ("", False), ("disocc", True)])
@@ -469,21 +477,26 @@ def test_compute_losses_vs_oracle(oracle_mod, dev, mask_occlusion, use_border):
     got, aux = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw,
                                      None if border is None else T(border, dev), mask_occlusion, 3,
                                      return_aux=True)
+    # Thresholded maps (occlusion, disocclusion): a pixel within fp32 noise of its threshold may
+    # fall on the other side, and at 4480 pixels ONE flipped pixel moves a scalar by 2e-4.  So the
+    # maps are compared for equality here (measured: no pixel differs on these inputs,
+    # tools/tolerance_probe.py), which is what lets the scalars hold north_star's 1e-5.
     for k in ("mask_fw", "mask_bw", "disocc_fw", "disocc_bw", "fb_occ_fw", "fb_occ_bw"):
-        # thresholded maps: allow a handful of pixels that sit within fp32 noise of the threshold
-        assert (N(aux[k]) != waux[k]).mean() < 1e-3, k
+        np.testing.assert_array_equal(N(aux[k]), waux[k], err_msg=k)
     close(aux["im2_warped"], waux["im2_warped"])
     assert set(got) == {"sym", "occ", "photo", "grad", "smooth_1st", "smooth_2nd", "fb", "ternary"}  # losses.py:60-85
     for k in ("ternary", "occ", "fb", "photo", "sym", "grad", "smooth_1st", "smooth_2nd"):
-        np.testing.assert_allclose(float(got[k]), want[k], rtol=2e-4, err_msg=k)
+        np.testing.assert_allclose(float(got[k]), want[k], rtol=1e-5, err_msg=k)
     # backward to the flows through census -> image_warp
     got["ternary"].backward()
     gim2 = oracle_mod.ternary_loss_grad(im1, waux["im2_warped"], waux["mask_fw"], 3)
     _, want_dfw = oracle_mod.image_warp_grad(gim2, im2, flow_fw, want_im=False)
     gim1 = oracle_mod.ternary_loss_grad(im2, waux["im1_warped"], waux["mask_bw"], 3)
     _, want_dbw = oracle_mod.image_warp_grad(gim1, im1, flow_bw, want_im=False)
-    close(ffw.grad, want_dfw, 1e-3, 1e-4 * np.abs(want_dfw).max())
-    close(fbw.grad, want_dbw, 1e-3, 1e-4 * np.abs(want_dbw).max())
+    # gradients: 1e-5 of the gradient's scale (measured 1.7e-6: per-tap rsq/rcp ulps through the
+    # t1 - t2 cancellation, then the warp's finite differences)
+    close(ffw.grad, want_dfw, 1e-5, 1e-5 * np.abs(want_dfw).max())
+    close(fbw.grad, want_dbw, 1e-5, 1e-5 * np.abs(want_dbw).max())
 
 
 @pytest.mark.parametrize("full_res,pyramid", [(False, True), (True, True), (False, False)])
@@ -505,9 +518,9 @@ def test_pyramid_loss_vs_oracle(oracle_mod, dev, full_res, pyramid):
     tf_ = [T(f, dev).requires_grad_(True) for f in fws]
     tb_ = [T(f, dev).requires_grad_(True) for f in bws]
     got, got_terms = unsupervised.pyramid_loss(T(im1, dev), T(im2, dev), T(border, dev), tf_, tb_, params)
-    np.testing.assert_allclose(float(got.detach()), want, rtol=2e-4)
+    np.testing.assert_allclose(float(got.detach()), want, rtol=1e-5)
     for k in unsupervised.LOSSES:
-        np.testing.assert_allclose(float(got_terms[k]), want_terms[k], rtol=2e-4, atol=1e-12, err_msg=k)
+        np.testing.assert_allclose(float(got_terms[k]), want_terms[k], rtol=1e-5, atol=1e-12, err_msg=k)
     assert float(got_terms["photo"]) == 0.0 and float(got_terms["sym"]) == 0.0      # no weight: not evaluated
     got.backward()
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in tf_[:levels if pyramid else 1])
@@ -525,7 +538,7 @@ def test_pyramid_loss_vs_oracle(oracle_mod, dev, full_res, pyramid):
         _, g_t = oracle_mod.image_warp_grad(g_im, i2, fws[0] * scale, want_im=False)
         g_s = oracle_mod.smoothness_loss_grad(fws[0] * scale, 2)
         wantg = 12.7 * scale * (g_t + 3.0 * g_s)
-        close(f0.grad, wantg, 1e-3, 1e-4 * np.abs(wantg).max())
+        close(f0.grad, wantg, 1e-5, 1e-5 * np.abs(wantg).max())
 
 
 @pytest.mark.parametrize("B,H,W,h,w", [(2, 64, 96, 16, 24), (1, 37, 53, 10, 14), (3, 8, 8, 2, 2), (1, 5, 300, 5, 75)])
@@ -552,7 +565,7 @@ def test_stacked_inputs_vs_oracle(oracle_mod, dev, B, H, W, h, w):
     g_warp = g[..., 8:11] + g[..., 11:14] * np.sign(warp - im1)
     _, g_full = oracle_mod.image_warp_grad(g_warp, im2, full, want_im=False)
     wantg = oracle_mod.resize_bilinear_grad(g_full + g[..., 6:8], h, w, mult=20.0)
-    close(f.grad, wantg, 1e-3, 1e-4 * np.abs(wantg).max())
+    close(f.grad, wantg, 1e-5, 1e-5 * np.abs(wantg).max())
 
 
 def test_resize_bilinear_vs_oracle(oracle_mod, dev):
@@ -628,7 +641,7 @@ def test_ternary_loss_warped_gradient(oracle_mod, dev, r):
     w = oracle_mod.image_warp(im2, flow)
     g_im = oracle_mod.ternary_loss_grad(im1, w, mask, r, gout=1.5)
     _, want = oracle_mod.image_warp_grad(g_im, im2, flow, want_im=False)
-    close(f1.grad, want, 1e-3, 1e-4 * np.abs(want).max())
+    close(f1.grad, want, 1e-5, 1e-5 * np.abs(want).max())
 
 
 def test_fused_loss_glue_matches_composition(oracle_mod, dev):
@@ -661,11 +674,12 @@ def test_fused_loss_glue_matches_composition(oracle_mod, dev):
         assert set(fused) == {"ternary", "sym", "occ", "smooth_2nd"}
         for k in fused:
             np.testing.assert_allclose(float(fused[k]), float(full[k]), rtol=1e-6, err_msg=k)
-            np.testing.assert_allclose(float(fused[k]), want[k], rtol=2e-4, err_msg=k)
+            np.testing.assert_allclose(float(fused[k]), want[k], rtol=1e-5, err_msg=k)
     # occlusion() (losses.py:125-134): unwarped magnitudes in the threshold
     got_fw, got_bw = losses.occlusion(ffw, fbw)
     want_fw, want_bw = oracle_mod.occlusion(flow_fw, flow_bw)
-    assert (N(got_fw) != want_fw).mean() < 1e-3 and (N(got_bw) != want_bw).mean() < 1e-3
+    np.testing.assert_array_equal(N(got_fw), want_fw)
+    np.testing.assert_array_equal(N(got_bw), want_bw)
     assert 0 < want_fw.mean() < 1
     only_smooth = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw, None, "", 1, terms=("smooth_1st",))
     assert set(only_smooth) == {"smooth_1st"}
@@ -729,9 +743,9 @@ def test_pyramid_loss_odd_extents_vs_oracle(oracle_mod, dev):
     tf_ = [T(f, dev).requires_grad_(True) for f in fws]
     tb_ = [T(f, dev).requires_grad_(True) for f in bws]
     got, got_terms = unsupervised.pyramid_loss(T(im1, dev), T(im2, dev), T(border, dev), tf_, tb_, params)
-    np.testing.assert_allclose(float(got.detach()), want, rtol=2e-4)       # small levels: see test_compute_losses_vs_oracle
+    np.testing.assert_allclose(float(got.detach()), want, rtol=1e-5)
     for k in ("ternary", "smooth_2nd", "fb", "occ"):
-        np.testing.assert_allclose(float(got_terms[k]), want_terms[k], rtol=2e-4, err_msg=k)
+        np.testing.assert_allclose(float(got_terms[k]), want_terms[k], rtol=1e-5, err_msg=k)
     got.backward()
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in tf_ + tb_)
 
@@ -771,7 +785,9 @@ def test_ternary_warped_gives_the_composed_set_of_gradients(dev):
         loss.backward()
         assert a.grad is None and b.grad is not None and f.grad is not None
         grads.append((b.grad, f.grad))
-    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    # the image gradient is a scatter-add (float atomics, order varies): equal up to rounding
+    close(grads[0][0], N(grads[1][0]), 1e-6, 1e-6 * float(grads[1][0].abs().max()))
+    assert torch.equal(grads[0][1], grads[1][1])
     # without a gradient request on im2 the fused kernels run and agree with the composition
     f1 = T(flow, dev).requires_grad_(True)
     l1 = losses.ternary_loss_warped(T(im1, dev), T(im2, dev), f1, mask, max_distance=3)

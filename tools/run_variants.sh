@@ -1,0 +1,9 @@
+# On the GPU box: one line per build in unflow_amd/variants (and the default build first).
+mkdir -p gpurun_out
+out=gpurun_out/variants_${1:-run}.txt
+timeout -k 10 120 python tools/corr_variant.py default >> $out 2>gpurun_out/variants_err.log || echo "default FAILED" >> $out
+for so in unflow_amd/variants/*.so; do
+  n=$(basename $so .so)
+  timeout -k 10 120 python tools/corr_variant.py $n $so >> $out 2>>gpurun_out/variants_err.log || echo "$n FAILED" >> $out
+done
+cat $out

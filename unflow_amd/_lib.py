@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libunflow_hip.so")
+# UNFLOW_HIP_LIB: another build of the SAME library (tools/variants.sh builds A/B variants of a
+# kernel with -D knobs); never a fallback -- a missing file raises like the default path does.
+LIB_PATH = os.environ.get("UNFLOW_HIP_LIB") or os.path.join(_HERE, "libunflow_hip.so")
 
 ABI_VERSION = 2      # UNFLOW_ABI_VERSION of include/unflow_hip.h
 UNFLOW_OK = 0

@@ -38,6 +38,7 @@ namespace unflow {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int S = 2;            // stride_2
 constexpr int R = 10;           // neighbourhood grid radius (max_displacement / stride_2)
@@ -58,6 +59,24 @@ static_assert(WIN % 4 == 0, "window must tile by 4");
 
 template <int N>
 using Int = std::integral_constant<int, N>;
+
+// f(Int<A>{}), f(Int<A+1>{}), ..., f(Int<B-1>{})
+template <int A, int B, class F>
+__device__ inline void static_for(F &&f) {
+  if constexpr (A < B) {
+    f(Int<A>{});
+    static_for<A + 1, B>(f);
+  }
+}
+// index of the nth set bit of mask (compile-time use)
+constexpr int nth_live(int mask, int nth) {
+  for (int b = 0; b < 31; ++b)
+    if ((mask >> b) & 1) {
+      if (nth == 0) return b;
+      --nth;
+    }
+  return 0;
+}
 
 __device__ inline __amdgpu_buffer_rsrc_t make_rsrc(const float *base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), (short)0, (int)bytes, 0x00020000);
@@ -722,6 +741,20 @@ constexpr int SW_LDS = 2 * SW_STAGE + SW_OUT;   // 37888 floats = 148 KB
 constexpr int KSTEPS = WIN / 4;                 // 6 K-steps per window row and tile
 constexpr int RING = 3;                         // live tiles per wave
 
+#ifdef UNFLOW_TUNE_STAMPS
+// Diagnostic build only (tools/variants.sh): shader-clock stamps of a few workgroups, read back
+// through unflow_debug_read_stamps().  [block 0..STAMP_BLOCKS)[wave 0 / wave 4][row][stamp]
+constexpr int STAMP_BLOCKS = 8, STAMP_ROWS = 128, STAMP_PER_ROW = 4;
+__device__ unsigned long long g_stamps[STAMP_BLOCKS * 2 * (STAMP_ROWS + 1) * STAMP_PER_ROW];
+#define UNFLOW_STAMP(ROW, WHICH)                                                                            \
+  do {                                                                                                      \
+    if (stamp_slot >= 0 && (threadIdx.x & 63) == 0 && (ROW) <= STAMP_ROWS)                                  \
+      g_stamps[(stamp_slot * (STAMP_ROWS + 1) + (ROW)) * STAMP_PER_ROW + (WHICH)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define UNFLOW_STAMP(ROW, WHICH) do {} while (0)
+#endif
+
 template <int VA, int VT, bool WRT1, bool FULL, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
     const std::conditional_t<F16, _Float16, float> *__restrict__ topdiff,
@@ -748,7 +781,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
   constexpr int T_PER_WAVE = (T_PIECES + NWAVES - 1) / NWAVES;
   // the DMA of the next row is issued during the first DSL K-steps of this row,
   // so that it has the remaining K-steps to land before the barrier
-  constexpr int DSL = (VA == 4 && VT == 4) ? 3 : KSTEPS;
+#ifndef UNFLOW_TUNE_DSL
+#define UNFLOW_TUNE_DSL 3
+#endif
+  constexpr int DSL = (VA == 4 && VT == 4) ? UNFLOW_TUNE_DSL : KSTEPS;
   constexpr int APS = (A_PER_WAVE + DSL - 1) / DSL;   // A pieces issued per K-step
   constexpr int TPS = (T_PER_WAVE + DSL - 1) / DSL;   // top pieces issued per K-step
 
@@ -890,14 +926,94 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
   };
 
   // Tile t = 2u + ph of this wave's parity lives in ring slot u % 3 while
-  // 4t - 10 <= w <= 4t + 13.
-  auto tile_in_slot = [&](int slot, int w) -> int {
-    const int u_hi = (w - 4 * ph + R) / 8;     // >= 0 because w >= 0 and ph <= 1
-    const int back = ((u_hi - slot) % RING + RING) % RING;
-    const int u = u_hi - back;
-    const int t = 2 * u + ph;
-    return (u >= 0 && t < ntiles && w <= 4 * t + TP - 1 + R) ? t : -1;
+  // 4t - 10 <= w <= 4t + 13, i.e. 8u <= v <= 8u + 23 with v = w - 4 ph + 10: the live tiles of
+  // row w are u_hi, u_hi - 1, u_hi - 2 with u_hi = v >> 3 (those that exist).  Everything a row
+  // needs besides its data -- the live tile of each ring slot and, per lane, the row of the top
+  // image that pairs (w, this lane's output row) -- is computed one row AHEAD, among the MFMAs of
+  // the last K-step: measured with cycle stamps, this scalar work cost 1000-1100 cycles at the top
+  // of every row with BOTH waves of a SIMD in it, i.e. with the matrix pipe idle.
+  struct RowState {
+    int tile[RING], b_row[RING];
+    bool b_rowok[RING];
   };
+  auto row_state = [&](int w) __attribute__((always_inline)) {
+    RowState rs;
+    const int v = w - 4 * ph + R;                // >= 0
+    const int u_hi = v >> 3, r3 = u_hi % RING;
+#pragma unroll
+    for (int sl = 0; sl < RING; ++sl) {
+      const int back = r3 - sl + (r3 < sl ? RING : 0);
+      const int u = u_hi - back;
+      const int t = 2 * u + ph;
+      rs.tile[sl] = (u >= 0 && t < ntiles) ? t : -1;
+      const int orow = 4 * rs.tile[sl] + oyl - w + R;
+      rs.b_rowok[sl] = rs.tile[sl] >= 0 && orow >= 0 && orow <= 2 * R;
+      rs.b_row[sl] = min(max(orow, 0), 2 * R) * (GW * RW);
+    }
+    return rs;
+  };
+
+  // ---- epilogue.  A finished tile is regrouped through LDS (`ob`: [channel][row 4][16 columns])
+  // by the waves that own it and stored as 64-byte row segments by all threads.  In the steady
+  // state both halves ride inside the K-steps of the FOLLOWING rows, a few instructions per
+  // K-step, with the row barriers that exist anyway between them:
+  //   after the barrier of row w    owners write the tile's accumulators to ob and clear them, while
+  //                                 their SIMD partners (the other tile parity) already compute row w+1
+  //   K-steps of row w+2            all threads store ob (one float4 per thread in K-steps 0..3),
+  //                                 the barrier of row w+1 standing between the two halves
+  // Tiles finish 4 rows apart, so ob is free again before the next tile needs it.  Tiles that
+  // finish too close to the last row (and those that finish ON it: all that are still live) take
+  // the synchronous path: dump, barrier, store, barrier.
+  float *const ob = lds + 2 * SW_STAGE;
+  const float inv_c = 1.f / (float)C;
+  const bool pow2_c = (C & (C - 1)) == 0;
+  // thread -> (channel, tile row, 4-column group) of its q-th float4 of the image: idx = tid + 512 q
+  const int st_c4 = threadIdx.x & 3, st_rr = (threadIdx.x >> 2) & 3, st_cl = threadIdx.x >> 4;   // + 32 q channels
+  auto store_piece = [&](int t, int q) __attribute__((always_inline)) {
+    const int idx = (int)threadIdx.x + NTHREADS * q;
+    const int c = c0 + st_cl + (NTHREADS / 16) * q;
+    const int oy = 4 * t + st_rr;
+    const int y = S * oy + cy, x = S * xs0 + st_c4 * 4;
+    if (c < C && oy < hs && x < W) {
+      float4 v = *reinterpret_cast<const float4 *>(ob + idx * 4);
+      if (pow2_c) {
+        v.x *= inv_c; v.y *= inv_c; v.z *= inv_c; v.w *= inv_c;
+      } else {
+        v.x /= (float)C; v.y /= (float)C; v.z /= (float)C; v.w /= (float)C;
+      }
+      auto *dst = gout + (item * C + c) * plane + (long long)y * W + x;
+      if constexpr (F16) {   // W % 4 == 0 and 8-byte aligned tensors are preconditions of this variant
+        *reinterpret_cast<f16x4 *>(dst) = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+      } else if (VA == 4 && x + 3 < W && (W & 3) == 0) {   // VA == 4: the host checked 16-byte alignment of gout
+        *reinterpret_cast<float4 *>(dst) = v;
+      } else {
+        dst[0] = v.x;
+        if (x + 1 < W) dst[1] = v.y;
+        if (x + 2 < W) dst[2] = v.z;
+        if (x + 3 < W) dst[3] = v.w;
+      }
+    }
+  };
+  static_assert(SW_OUT / 4 == 4 * NTHREADS, "four float4 per thread");
+  const int dump_off = (4 * k * TP + oyl) * RW + b_col;   // + (m*16 + j) * TP * RW
+  // accumulators of ring slot SLOT -> ob, cleared (the slot's next tile starts on the next row).
+  // A macro, not a lambda: with the accumulator array captured by a lambda that selects the slot at
+  // run time the compiler keeps the whole array in scratch memory (10x slower, measured).
+#define UNFLOW_DUMP_TILE(SLOT)                                                             \
+  do {                                                                                     \
+    const int slot_ = (SLOT);                                                              \
+    _Pragma("unroll") for (int sl = 0; sl < RING; ++sl) {                                  \
+      if (sl == slot_) {                                                                   \
+        _Pragma("unroll") for (int m = 0; m < MTS; ++m) {                                  \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
+            ob[dump_off + (m * 16 + j) * TP * RW] = acc[sl][m][j]; /* scaled when stored */ \
+          acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+        }                                                                                  \
+      }                                                                                    \
+    }                                                                                      \
+  } while (0)
+  int dump_tile = -1;          // tile written to ob after the previous row's barrier  (workgroup-uniform)
+  int store_tile = -1;         // tile whose image in ob is stored during this row    (workgroup-uniform)
 
   if constexpr (F16) {
     load_row(0);
@@ -905,23 +1021,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
   } else {
     issue_row(0, lds);
   }
+  RowState rs = row_state(0);
   __syncthreads();
+#ifdef UNFLOW_TUNE_STAMPS
+  // blocks 0..3 (first round) and 4 blocks of a later round, waves 0 and 4 (SIMD partners), WRT1 launch only
+  int stamp_slot = -1;
+  {
+    const int bsel = (int)blockIdx.x < 4 ? (int)blockIdx.x : ((int)blockIdx.x >= 600 && (int)blockIdx.x < 604 ? (int)blockIdx.x - 596 : -1);
+    if (WRT1 && bsel >= 0 && (wave == 0 || wave == 4)) stamp_slot = bsel * 2 + (wave >> 2);
+  }
+  UNFLOW_STAMP(STAMP_ROWS, 0);     // end of the prologue
+#endif
   for (int w = 0; w < hs; ++w) {
+    UNFLOW_STAMP(w, 0);            // top of the row (after the previous barrier / epilogue)
     const float *cur = lds + (w & 1) * SW_STAGE;
     float *nxt = lds + ((w + 1) & 1) * SW_STAGE;
     const bool more = w + 1 < hs;
     if (F16 && more) load_row(w + 1);
-    // per ring slot: live tile, LDS row offset of the top image row that pairs
-    // (w, this lane's output row), validity
-    int tile[RING], b_row[RING];
-    bool b_rowok[RING];
-#pragma unroll
-    for (int sl = 0; sl < RING; ++sl) {
-      tile[sl] = tile_in_slot(sl, w);
-      const int orow = 4 * tile[sl] + oyl - w + R;
-      b_rowok[sl] = tile[sl] >= 0 && orow >= 0 && orow <= 2 * R;
-      b_row[sl] = min(max(orow, 0), 2 * R) * (GW * RW);
-    }
+    RowState rn;                   // state of row w + 1, produced in the last K-step
 
     // A and B fragments are read one K-step ahead (two register sets), so the
     // LDS latency of step s+1 hides behind the MFMAs of step s.
@@ -932,7 +1049,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
 #pragma unroll
       for (int m = 0; m < MTS; ++m) abuf[s4 & 1][m] = ap[m * 16 * ACS];
 #pragma unroll
-      for (int sl = 0; sl < RING; ++sl) bbuf[s4 & 1][sl] = cur[b_row[sl] + b_dx[s4]];   // masked at use
+      for (int sl = 0; sl < RING; ++sl) bbuf[s4 & 1][sl] = cur[rs.b_row[sl] + b_dx[s4]];   // masked at use
     };
     auto kstep = [&](auto S4) {
       constexpr int s4 = decltype(S4)::value;
@@ -940,79 +1057,509 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
       const bool dxok = b_dxok & (1u << s4);
 #pragma unroll
       for (int sl = 0; sl < RING; ++sl) {
-        if (tile[sl] >= 0) {                       // wave-uniform
-          const float b = (dxok && b_rowok[sl]) ? bbuf[s4 & 1][sl] : 0.f;
+        if (rs.tile[sl] >= 0) {                    // wave-uniform
+          const float b = (dxok && rs.b_rowok[sl]) ? bbuf[s4 & 1][sl] : 0.f;
 #pragma unroll
           for (int m = 0; m < MTS; ++m)
             if (FULL || m < nmt)
               acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s4 & 1][m], b, acc[sl][m], 0, 0, 0);
         }
+        // rider: a slice of the pending tile store behind a group of MFMAs
+        if (sl == 1 && s4 < 4 && store_tile >= 0) store_piece(store_tile, s4);
       }
+#ifndef UNFLOW_TUNE_NODMA
       if (!F16 && more) issue_slice(S4, w + 1, nxt);
+#endif
+      if constexpr (s4 == KSTEPS - 1) rn = row_state(w + 1);
       __builtin_amdgcn_sched_barrier(0);
     };
     load_ab(Int<0>{});
+    UNFLOW_STAMP(w, 1);            // setup done, first fragments requested
     kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
     if (F16 && more) store_row(nxt);
+    UNFLOW_STAMP(w, 2);            // K-steps issued
     __syncthreads();
+    UNFLOW_STAMP(w, 3);            // through the barrier
 
-    // ---- tiles whose last window row was w: regroup through LDS to
-    // [channel][row 4][16 columns] and store 64-byte row segments.
-    const int t_lo = max(0, (w - R) / TP);         // first tile that can still be live
-    for (int t = t_lo; t < ntiles && 4 * t - R <= w; ++t) {
-      const int fin_row = min(hs - 1, 4 * t + TP - 1 + R);
-      if (fin_row != w) continue;                  // uniform over the workgroup
-      float *ob = lds + 2 * SW_STAGE;
-      const float inv = 1.f / (float)C;
-      const bool pow2 = (C & (C - 1)) == 0;
-      if ((t & 1) == ph) {
-        const int slot = (t >> 1) % RING;
+    // ---- epilogue pipeline (see above); everything here is workgroup-uniform control
+    store_tile = dump_tile;        // written to ob during this row: stored during the next one
+    dump_tile = -1;
+    rs = rn;
+#ifdef UNFLOW_TUNE_NOSTORE
+    if (C > 0) { store_tile = -1; continue; }      // diagnostic: always true at run time, opaque to the compiler
+#endif
+    if (more) {
+      // at most one tile ends on a row that is not the last: 4 t + 13 == w
+      const int t = (w - (TP - 1 + R)) >> 2;
+      if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
+        if (w + 2 <= hs - 1) {                     // room for the two riding rows
+          if ((t & 1) == ph) UNFLOW_DUMP_TILE((t >> 1) % RING);
+          dump_tile = t;
+        } else {                                   // too close to the end: synchronous
+          if (store_tile >= 0) {                   // (cannot happen with finishing rows 4 apart; kept for safety)
 #pragma unroll
-        for (int sl = 0; sl < RING; ++sl) {
-          if (sl == slot) {
-#pragma unroll
-            for (int m = 0; m < MTS; ++m) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int cl = m * 16 + 4 * k + j;
-                const float v = acc[sl][m][j];
-                ob[(cl * TP + oyl) * RW + b_col] = v;      // scaled by 1/C when the image is stored
-                acc[sl][m][j] = 0.f;
-              }
-            }
+            for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
+            store_tile = -1;
+            __syncthreads();
           }
+          if ((t & 1) == ph) UNFLOW_DUMP_TILE((t >> 1) % RING);
+          __syncthreads();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) store_piece(t, q);
+          __syncthreads();
         }
       }
-      __syncthreads();
-      for (int idx = threadIdx.x; idx < SW_OUT / 4; idx += NTHREADS) {
-        const int c4 = idx % (RW / 4);
-        const int rr = (idx / (RW / 4)) % TP;
-        const int cl = idx / (RW / 4 * TP);
-        const int c = c0 + cl;
-        const int oy = 4 * t + rr;
-        const int y = S * oy + cy, x = S * xs0 + c4 * 4;
-        if (c >= C || oy >= hs || x >= W) continue;
-        float4 v = *reinterpret_cast<const float4 *>(ob + idx * 4);
-        if (pow2) {
-          v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
-        } else {
-          v.x /= (float)C; v.y /= (float)C; v.z /= (float)C; v.w /= (float)C;
-        }
-        auto *dst = gout + (item * C + c) * plane + (long long)y * W + x;
-        if constexpr (F16) {   // W % 4 == 0 and 8-byte aligned tensors are preconditions of this variant
-          *reinterpret_cast<f16x4 *>(dst) = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-        } else if (VA == 4 && x + 3 < W && (W & 3) == 0) {   // VA == 4: the host checked 16-byte alignment of gout
-          *reinterpret_cast<float4 *>(dst) = v;
-        } else {
-          dst[0] = v.x;
-          if (x + 1 < W) dst[1] = v.y;
-          if (x + 2 < W) dst[2] = v.z;
-          if (x + 3 < W) dst[3] = v.w;
-        }
+    } else {
+      // last row: flush the pipeline, then every tile that is still live ends here
+      if (store_tile >= 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
+        store_tile = -1;
+        __syncthreads();
       }
-      __syncthreads();
+      const int t_first = max(0, (w - (TP - 1 + R) + 3) >> 2);       // first t with 4 t + 13 >= w
+      for (int t = t_first; t < ntiles; ++t) {
+        if ((t & 1) == ph) UNFLOW_DUMP_TILE((t >> 1) % RING);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store_piece(t, q);
+        __syncthreads();
+      }
     }
   }
+}
+
+#undef UNFLOW_DUMP_TILE
+
+// ===========================================================================
+// Backward, second generation (f32, 16-byte aligned rows, C % 128 == 0): the same row sweep
+// as corr_mfma_bwd_kernel, rebuilt around what cycle stamps of that kernel showed
+// (tools/stamps.py, profiles/r02_bwd_stamps.txt):
+//   * the two waves that share a SIMD run the same instruction stream in lockstep behind the
+//     row barrier, so every stretch of non-MFMA instructions (fragment reads, B masks, DMA
+//     issue, the per-row scalar set-up, the epilogue) is a stretch with the matrix pipe idle:
+//     35.7 instead of 32 cycles per MFMA inside the K-steps, ~2000 cycles per row around them;
+//   * a workgroup needs 148 KB of LDS, so a CU holds one: its launch, prologue fetch and the
+//     drain of its last stores are exposed between workgroups (6 % of the kernel).
+// Hence:
+//   * MFMA-dense streams: a row runs one of seven branch-free K-step bodies (one per set of live
+//     ring slots), in which every MFMA is followed by ONE small piece of the other work, pinned
+//     with scheduling barriers -- each wave alone can then keep the pipe busy;
+//   * no B masks: the top image has an all-zero 22nd row and 22nd displacement column (the DMA
+//     range check writes them) and an invalid (row, dx') simply points there;
+//   * the scalar state of a row is computed one row ahead, inside the last K-step;
+//   * finished tiles leave through ob while the next rows compute (owners dump after the row's
+//     barrier, everybody stores inside the K-steps of the row after next);
+//   * persistent workgroups: one per CU walks its share of the (pair, row class, channel group,
+//     strip) items; the first row of the next item is fetched during the last row of this one;
+//   * LDS images without the 4-way (top) and 2-way (A) bank conflicts of the first kernel:
+//     top row stride 356, A channel groups of 8 start alternately 0 / 1 floats in.
+// ===========================================================================
+namespace b2 {
+constexpr int TROWS2 = TROWS + 1;               // 22: + one all-zero row
+constexpr int TDX2 = GW + 1;                    // 22: + one all-zero displacement column
+constexpr int ZERO_ROW = TROWS, ZERO_DX = GW;   // 21
+constexpr int TRS = TDX2 * RW + 4;              // 356 floats per top-image row: 2-way instead of 4-way conflicts
+constexpr int T_IMAGE = TROWS2 * TRS;           // 7832
+constexpr int T_PIECES = (T_IMAGE + 255) / 256; // 31 DMA pieces of 1 KiB
+constexpr int T_STAGE = T_PIECES * 256;         // 7936
+constexpr int AG = 8 * ACS;                     // 480 floats: a group of 8 channel rows
+constexpr int A_PIECE_F = AG / 2;               // 240 floats = 60 lanes x 4: a piece never crosses a group
+constexpr int A_PIECES = CWS / 8 * 2;           // 32
+constexpr int A_STAGE = (CWS * ACS + 1 + 63) / 64 * 64;   // 7744 (odd groups start one float later)
+constexpr int STAGE2 = A_STAGE + T_STAGE;        // 15680 floats
+constexpr int LDS_FLOATS = 2 * STAGE2 + SW_OUT;  // 39552 floats = 158208 B
+constexpr int A_PER_WAVE = A_PIECES / NWAVES;   // 4
+constexpr int T_PER_WAVE = (T_PIECES + NWAVES - 1) / NWAVES;   // 4 (wave 7: 3)
+static_assert(A_PIECES % NWAVES == 0 && 4 * LDS_FLOATS <= 160 * 1024, "LDS budget");
+// A fragment (ds_read_b32, lanes 0..31 = 16 channels x 2 window columns): channel n sits at
+// n*60 + (n>>3): the 8 channels of a group take the 8 banks = 0 mod 4 (60 = 28 mod 32), the next
+// group the banks = 1 mod 4, the second window column (+2 floats) the banks = 2, 3 mod 4.
+static_assert(ACS % 32 == 28, "A image bank pattern");
+}  // namespace b2
+
+// Barriers of the second-generation kernel, written out: the compiler's own wait-count insertion
+// knows nothing about the LDS side of an LDS-DMA (a plain __syncthreads() came out as vmcnt(9) in
+// front of the very first row), and its fences wait for stores nobody depends on.
+//   _DMA: every LDS-DMA (and everything older) of this wave has landed, LDS traffic done
+//   _LDS: only this wave's LDS reads / writes are done (dump -> store hand-over through ob)
+#define UNFLOW_BARRIER_DMA() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define UNFLOW_BARRIER_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+#ifdef UNFLOW_TUNE_NODMA
+#define UNFLOW_TUNE_NODMA2 (C > 0)       // diagnostic: always true at run time, opaque to the compiler
+#else
+#define UNFLOW_TUNE_NODMA2 false
+#endif
+template <bool WRT1>
+__global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float *__restrict__ topdiff,
+                                                                     const float *__restrict__ fin,
+                                                                     float *__restrict__ gout, int C, int H, int W,
+                                                                     int nbx, int nch, int nitems) {
+  using namespace b2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  __builtin_assume(wave >= 0 && wave < NWAVES);
+  const int cx = wave & 1, tx = (wave >> 1) & 1, ph = wave >> 2;
+  const long long plane = (long long)H * W;
+  const int row_bytes = S * W * 4;             // one class row further down
+
+  // items of this workgroup: XCD x (blocks b = x mod 8) walks the contiguous range
+  // [x n/8, (x+1) n/8) so that its L2 sees neighbouring strips of the same pairs
+  const bool xcd_split = (nitems & 7) == 0 && (gridDim.x & 7) == 0;
+  const int it_stride = xcd_split ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  const int it_first = xcd_split ? (int)(blockIdx.x & 7) * (nitems >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int it_end = xcd_split ? ((int)(blockIdx.x & 7) + 1) * (nitems >> 3) : nitems;
+  if (it_first >= it_end) return;
+
+  const int k = lane >> 4, n = lane & 15;
+  const int oyl = n >> 2, oxl = n & 3;
+  const int b_col = S * (tx * TP + oxl) + cx;  // column of this lane's output position in the region
+  // A fragment of M-tile m, K-step q:  a_off + m*16*ACS + 8*q   (16 channels = two groups)
+  const int a_off = n * ACS + (n >> 3) + S * (tx * TP + k) + cx;
+  float *const ob = lds + 2 * STAGE2;
+  const int dump_off = (4 * k * TP + oyl) * RW + b_col;   // + (m*16 + j) * TP * RW
+  const int st_c4 = threadIdx.x & 3, st_rr = (threadIdx.x >> 2) & 3, st_cl = threadIdx.x >> 4;   // + 32 q channels
+  const int st_voff = (int)((st_cl * plane + (long long)(S * st_rr) * W + st_c4 * 4) * 4);        // inside the channel group
+  const float inv_c = 1.f / (float)C;
+  const bool pow2_c = (C & (C - 1)) == 0;
+
+  // ---- what the DMA of one item needs.  The last row of an item fetches nothing for it any more,
+  // so its top is where the description of the NEXT item replaces this one.
+  struct Fetch {
+    __amdgpu_buffer_rsrc_t rtop, rin;
+    unsigned a_voff[A_PER_WAVE];   // channel plane + column of the lane's A segment (or OOB); the row is the SGPR offset
+    int t_base[T_PER_WAVE];        // byte offset of the lane's top segment at sweep row 0 (linear in w)
+    int cy, hs;
+  };
+  // lane -> (row of the top image, valid) of its top pieces: the same for every item
+  int t_orow[T_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < T_PER_WAVE; ++j) {
+    const int f = ((wave + NWAVES * j) * 64 + lane) * 4;
+    const int orow = f / TRS, rem = f - orow * TRS;
+    const bool cell = wave + NWAVES * j < T_PIECES && orow < TROWS && rem / RW < GW;   // not the zero row / column / pad
+    t_orow[j] = cell ? orow : (1 << 28);
+  }
+  // lanes that take part in A piece j: the 4 pad floats that end every 60-float channel row are never
+  // read and must not be written either -- the last one of an odd (shifted) group is the first float
+  // of the next group
+  unsigned a_lanes = 0;
+#pragma unroll
+  for (int j = 0; j < A_PER_WAVE; ++j) {
+    const int g = lane * 4 + ((wave + NWAVES * j) & 1) * A_PIECE_F;
+    if (lane < A_PIECE_F / 4 && g % ACS < ROWF) a_lanes |= 1u << j;
+  }
+  struct Item {
+    int bx, chg, cy;
+    long long pair;
+  };
+  auto decode = [&](int it) {
+    Item d;
+    d.bx = it % nbx;
+    it /= nbx;
+    d.chg = it % nch;
+    it /= nch;
+    d.cy = it & 1;
+    d.pair = it >> 1;
+    return d;
+  };
+  auto make_fetch = [&](const Item &d) {
+    Fetch f;
+    f.cy = d.cy;
+    f.hs = (H - d.cy + S - 1) / S;
+    const int xs0 = d.bx * RX, c0 = d.chg * CWS;
+    f.rtop = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(topdiff + d.pair * (GW * GW) * plane), (short)0,
+                                               (int)(GW * GW * plane * 4), 0x00020000);
+    f.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fin + (d.pair * C + c0) * plane), (short)0,
+                                              (int)((long long)(C - c0) * plane * 4), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+      const int p = wave + NWAVES * j;                 // piece: group p >> 1, half p & 1
+      const int g = lane * 4 + (p & 1) * A_PIECE_F;    // float inside the group (lanes >= 60 take no part)
+      const int r8 = g / ACS, x = g - r8 * ACS;
+      const int c = (p >> 1) * 8 + r8;
+      const int X = S * (xs0 - R) + x;
+      f.a_voff[j] = (X >= 0 && X < W) ? (unsigned)((c * plane + X) * 4) : OOB;     // outside the image: zeros
+    }
+#pragma unroll
+    for (int j = 0; j < T_PER_WAVE; ++j) {
+      const int fl = ((wave + NWAVES * j) * 64 + lane) * 4;     // float of the top image: [orow][dx'][col]
+      const int orow = min(fl / TRS, TROWS - 1), rem = fl % TRS;
+      const int dxp = min(rem / RW, GW - 1), col = rem % RW;
+      int dyp, Y0, Xt;
+      if (WRT1) {   // position = window position: row w, column shifted by -dx
+        dyp = orow;
+        Y0 = d.cy;
+        Xt = S * xs0 - S * (dxp - R) + col;
+      } else {      // position = output position: row oy = w - R + orow
+        dyp = 2 * R - orow;
+        Y0 = S * (orow - R) + d.cy;
+        Xt = S * xs0 + col;
+      }
+      const bool ok = Xt + 3 >= 0 && Xt < W;     // (a straddling piece only feeds masked window columns)
+      f.t_base[j] = ok ? (int)((((long long)(dyp * GW + dxp) * H + Y0) * W + Xt) * 4) : (int)0x80000000;
+    }
+    return f;
+  };
+  // one DMA piece of window row w of the item described by f into `stage`
+  auto issue_a = [&](const Fetch &f, int j, int w, float *stage) {
+    const int p = wave + NWAVES * j;
+    float *dst = stage + (p >> 1) * AG + ((p >> 1) & 1) + (p & 1) * A_PIECE_F;
+    if (a_lanes & (1u << j)) dma<4>(f.rin, dst, f.a_voff[j], (S * w + f.cy) * W * 4);
+  };
+  auto issue_t = [&](const Fetch &f, int j, int w, float *stage) {
+    if (wave + NWAVES * j < T_PIECES) {
+      const int oy = w - R + t_orow[j];
+      const unsigned voff = (oy >= 0 && oy < f.hs && f.t_base[j] != (int)0x80000000) ? (unsigned)(f.t_base[j] + w * row_bytes) : OOB;
+      dma<4>(f.rtop, stage + A_STAGE + (wave + NWAVES * j) * 256, voff, 0);
+    }
+  };
+
+  f32x4 acc[RING][MTS];
+#pragma unroll
+  for (int sl = 0; sl < RING; ++sl)
+#pragma unroll
+    for (int m = 0; m < MTS; ++m) acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#define UNFLOW_DUMP_TILE2(SLOT)                                                            \
+  do {                                                                                     \
+    const int slot_ = (SLOT);                                                              \
+    _Pragma("unroll") for (int sl = 0; sl < RING; ++sl) {                                  \
+      if (sl == slot_) {                                                                   \
+        _Pragma("unroll") for (int m = 0; m < MTS; ++m) {                                  \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
+            ob[dump_off + (m * 16 + j) * TP * RW] = acc[sl][m][j]; /* scaled when stored */ \
+          acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
+        }                                                                                  \
+      }                                                                                    \
+    }                                                                                      \
+  } while (0)
+
+  Item cur_item = decode(it_first);
+  Fetch fc = make_fetch(cur_item);
+  int rowc = 0;                                  // rows done by this workgroup: stage = rowc & 1
+#pragma unroll
+  for (int j = 0; j < A_PER_WAVE; ++j) issue_a(fc, j, 0, lds);
+#pragma unroll
+  for (int j = 0; j < T_PER_WAVE; ++j) issue_t(fc, j, 0, lds);
+
+  UNFLOW_BARRIER_DMA();          // row 0 of the first item has landed
+#ifdef UNFLOW_TUNE_STAMPS
+  int stamp_slot = -1;           // workgroups 0..3 and 128..131, waves 0 and 4 (SIMD partners), WRT1 launch, first item
+  {
+    const int bsel = (int)blockIdx.x < 4 ? (int)blockIdx.x : ((int)blockIdx.x >= 128 && (int)blockIdx.x < 132 ? (int)blockIdx.x - 124 : -1);
+    if (WRT1 && bsel >= 0 && (wave == 0 || wave == 4)) stamp_slot = bsel * 2 + (wave >> 2);
+  }
+  UNFLOW_STAMP(STAMP_ROWS, 0);
+#endif
+
+  for (int it = it_first; it < it_end; it += it_stride) {
+    const int cy = cur_item.cy, hs = fc.hs, ntiles = (hs + TP - 1) / TP;
+    const int xs0 = cur_item.bx * RX, c0 = cur_item.chg * CWS;
+    const long long pair = cur_item.pair;
+    const bool last_item = it + it_stride >= it_end;
+    // B fragment of K-step q: dx' as an LDS offset; an invalid dx' (outside the window, or -- for the
+    // gradient wrt input 1 -- a window column outside the image) points at the all-zero column
+    int b_dx[KSTEPS];
+#pragma unroll
+    for (int q = 0; q < KSTEPS; ++q) {
+      const int dxp = WRT1 ? (oxl + 2 * R - k - 4 * q) : (k - oxl + 4 * q);
+      const int Xw = S * (xs0 + tx * TP - R + 4 * q + k) + cx;   // full-resolution column of the window position
+      const bool ok = dxp >= 0 && dxp <= 2 * R && (!WRT1 || (Xw >= 0 && Xw < W));
+      b_dx[q] = (ok ? dxp : ZERO_DX) * RW + b_col + A_STAGE;
+    }
+    // state of a row: the live tile of each ring slot (tile t = 2u + ph of this wave's parity lives
+    // in slot u % 3 while 8u <= w - 4 ph + 10 <= 8u + 23) and, per lane, the LDS row of the top image
+    // that pairs (w, this lane's output row) -- the all-zero row when there is none
+    struct RowState {
+      int tile[RING], b_row[RING];
+    };
+    auto row_state = [&](int w) __attribute__((always_inline)) {
+      RowState rs;
+      const int v = w - 4 * ph + R;              // >= 0
+      const int u_hi = v >> 3, r3 = u_hi % RING;
+#pragma unroll
+      for (int sl = 0; sl < RING; ++sl) {
+        const int back = r3 - sl + (r3 < sl ? RING : 0);
+        const int u = u_hi - back;
+        const int t = 2 * u + ph;
+        rs.tile[sl] = (u >= 0 && t < ntiles) ? t : -1;
+        const int orow = 4 * rs.tile[sl] + oyl - w + R;
+        rs.b_row[sl] = ((rs.tile[sl] >= 0 && orow >= 0 && orow <= 2 * R) ? orow : ZERO_ROW) * TRS;
+      }
+      return rs;
+    };
+    // the tile image leaves through a buffer descriptor of this item's gradient planes (channel
+    // group c0 of the pair): one per-lane offset (channel, tile row, 4-column group), everything
+    // else -- the tile, the 32-channel step of the float4 index, the strip -- in the scalar offset
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
+        gout + (pair * C + c0) * plane, (short)0, (int)((long long)(C - c0) * plane * 4), 0x00020000);
+    auto store_piece = [&](int t, int q) __attribute__((always_inline)) {
+      const int idx = (int)threadIdx.x + NTHREADS * q;
+      const int oy = 4 * t + st_rr;
+      const int x = S * xs0 + st_c4 * 4;
+      if (oy < hs && x < W) {                    // C % 128 == 0: every channel exists
+        f32x4 v = *reinterpret_cast<const f32x4 *>(ob + idx * 4);
+        if (pow2_c) v *= inv_c;
+        else v /= (float)C;
+        const int soff = (int)(((long long)(NTHREADS / 16) * q * plane + (long long)(S * 4 * t + cy) * W + S * xs0) * 4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, st_voff, soff, 0);
+      }
+    };
+
+    RowState rs = row_state(0);
+    int dump_tile = -1;          // tile written to ob after the previous row's barrier   (workgroup-uniform)
+    int store_tile = -1;         // tile whose image in ob is stored during this row      (workgroup-uniform)
+    // (row 0 of this item has landed: fetched before the loop, or during the last row of the previous
+    // item and waited for at that row's barrier)
+
+    for (int w = 0; w < hs; ++w, ++rowc) {
+      UNFLOW_STAMP(rowc, 0);
+      const float *cur = lds + (rowc & 1) * STAGE2;
+      float *nxt = lds + ((rowc + 1) & 1) * STAGE2;
+      const bool more = w + 1 < hs;
+      if (!more && !last_item) {                 // the fetch of the next item's first row rides this row
+        cur_item = decode(it + it_stride);
+        fc = make_fetch(cur_item);
+      }
+      const bool fetch = more || !last_item;
+      const int wn = more ? w + 1 : 0;
+      RowState rn;                               // state of row w + 1, produced in the last K-step
+
+      // ---- one row: 6 K-steps x 2 halves of the M-tiles x 3 ring slots, 4 MFMAs each; behind every
+      // half a short chunk of the other work (fragment reads of the next K-step, one DMA piece of
+      // the next row, a slice of a pending tile store, the next row's state), pinned there by
+      // scheduling barriers so that it never collects into a long stretch without MFMAs.
+      float abuf[MTS], bbuf[2][RING];
+      auto read_a = [&](auto Q, auto M) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value, m = decltype(M)::value;
+        abuf[m] = cur[a_off + m * 16 * ACS + 4 * S * q];
+      };
+      auto read_b = [&](auto Q, auto SL) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value, sl = decltype(SL)::value;
+        bbuf[q & 1][sl] = cur[rs.b_row[sl] + b_dx[q]];
+      };
+      // The other work of K-step q comes in two chunks, one behind each half of the M-tiles.  The A
+      // fragments are single-buffered: M-tiles 0..3 are free once half 0 is through and are re-read
+      // (for K-step q+1) right then, M-tiles 4..7 behind half 1 -- up to 12 MFMAs ahead of their use.
+      auto chunk = [&](auto Q, auto H) __attribute__((always_inline)) {
+        constexpr int q = decltype(Q)::value, h = decltype(H)::value;
+        if constexpr (q + 1 < KSTEPS) static_for<4 * h, 4 * h + 4>([&](auto M) { read_a(Int<q + 1>{}, M); });
+        if constexpr (h == 0) {
+          if constexpr (q + 1 < KSTEPS) static_for<0, RING>([&](auto SL) { read_b(Int<q + 1>{}, SL); });
+          if constexpr (q < A_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_a(fc, q, wn, nxt); }
+        } else {
+          if constexpr (q < T_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_t(fc, q, wn, nxt); }
+          // the pending tile store goes LAST among the row's vector-memory operations (K-steps 4, 5:
+          // behind the last DMA piece), so that the barrier can wait for the DMA without the stores
+          if constexpr (q >= KSTEPS - 2) {
+            if (store_tile >= 0) {
+              store_piece(store_tile, 2 * (q - (KSTEPS - 2)));
+              store_piece(store_tile, 2 * (q - (KSTEPS - 2)) + 1);
+            }
+          }
+          if constexpr (q == KSTEPS - 1) rn = row_state(w + 1);
+        }
+      };
+      // wave-uniform (forced into scalar registers: the compiler would otherwise rebuild them from a
+      // vector compare in front of every block)
+      const bool live0 = __builtin_amdgcn_readfirstlane(rs.tile[0]) >= 0;
+      const bool live1 = __builtin_amdgcn_readfirstlane(rs.tile[1]) >= 0;
+      const bool live2 = __builtin_amdgcn_readfirstlane(rs.tile[2]) >= 0;
+      // first fragments (their latency is exposed once per row)
+      static_for<0, MTS>([&](auto M) { read_a(Int<0>{}, M); });
+      static_for<0, RING>([&](auto SL) { read_b(Int<0>{}, SL); });
+      __builtin_amdgcn_sched_barrier(0);
+      UNFLOW_STAMP(rowc, 1);
+      static_for<0, KSTEPS>([&](auto Q) {
+        constexpr int q = decltype(Q)::value;
+#ifdef UNFLOW_TUNE_PRIO   // measured: +1 % without the DMA, -3 % with it; not used
+        // The older half of the workgroup (waves 0..3) wins every arbitration for the SIMD it shares
+        // with a wave of the younger half, finishes its row ~1700 cycles early and leaves the partner
+        // to work off its MFMAs alone, which a single wave cannot do at the full rate.  Raising the
+        // younger half's priority in every other K-step lets both halves reach the barrier together.
+        if (ph == 1) {
+          if constexpr (q & 1) __builtin_amdgcn_s_setprio(1);
+          else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
+        static_for<0, 2>([&](auto H) {
+          constexpr int m0 = decltype(H)::value * (MTS / 2);
+          static_for<0, RING>([&](auto SL) {
+            constexpr int sl = decltype(SL)::value;
+            // a dead ring slot skips its MFMAs: one wave-uniform branch per 4
+            if (sl == 0 ? live0 : (sl == 1 ? live1 : live2)) {
+#pragma unroll
+              for (int m = m0; m < m0 + MTS / 2; ++m)
+                acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[m], bbuf[q & 1][sl], acc[sl][m], 0, 0, 0);
+            }
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          chunk(Q, H);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      });
+      // Row barrier.  vmcnt counts loads, LDS-DMA and stores together, in issue order: the four tile
+      // stores of this row are this wave's youngest operations, and waiting for their
+      // acknowledgement (microseconds under load) is not needed for anything -- only the DMA of the
+      // next row must have landed.  (Every wave issues all four: each holds lanes of tile row 0.)
+      UNFLOW_STAMP(rowc, 2);
+      if (store_tile >= 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else UNFLOW_BARRIER_DMA();
+      UNFLOW_STAMP(rowc, 3);
+
+      // ---- epilogue pipeline; workgroup-uniform control
+      store_tile = dump_tile;      // dumped after the previous barrier: stored during the next row
+      dump_tile = -1;
+      rs = rn;
+#ifdef UNFLOW_TUNE_NOSTORE
+      if (C > 0) { store_tile = -1; continue; }    // diagnostic: always true at run time, opaque to the compiler
+#endif
+      if (more) {
+        // at most one tile ends on a row that is not the last: 4 t + 13 == w
+        const int t = (w - (TP - 1 + R)) >> 2;
+        if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
+          if (w + 2 <= hs - 1) {                 // room for the two riding rows
+            if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
+            dump_tile = t;
+          } else {                               // too close to the end: synchronous
+            if (store_tile >= 0) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
+              store_tile = -1;
+              UNFLOW_BARRIER_LDS();
+            }
+            if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
+            UNFLOW_BARRIER_LDS();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) store_piece(t, q);
+            UNFLOW_BARRIER_LDS();
+          }
+        }
+      } else {
+        // last row: flush the pipeline, then every tile that is still live ends here
+        if (store_tile >= 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
+          store_tile = -1;
+          UNFLOW_BARRIER_LDS();
+        }
+        const int t_first = max(0, (w - (TP - 1 + R) + 3) >> 2);     // first t with 4 t + 13 >= w
+        for (int t = t_first; t < ntiles; ++t) {
+          if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
+          UNFLOW_BARRIER_LDS();
+#pragma unroll
+          for (int q = 0; q < 4; ++q) store_piece(t, q);
+          if (t + 1 < ntiles) UNFLOW_BARRIER_LDS();   // ob is rewritten by the next tile
+        }
+      }
+    }
+  }
+#undef UNFLOW_DUMP_TILE2
+#undef UNFLOW_BARRIER_DMA
+#undef UNFLOW_BARRIER_LDS
 }
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1022,6 +1569,16 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // instantiations of one kernel template share a function type, and a flag keyed on the type
 // would be set for the first only.  A failure is returned, never remembered.
 constexpr int kMaxDevices = 64;
+// compute units of the current device (the persistent kernels launch one workgroup per CU)
+inline int num_cus() {
+  static std::atomic<int> cached[kMaxDevices];
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  if (dev >= 0 && dev < kMaxDevices && (n = cached[dev].load(std::memory_order_relaxed)) > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0 && dev < kMaxDevices) cached[dev].store(n, std::memory_order_relaxed);
+  return n;
+}
 template <auto KERNEL>
 int reserve_lds(size_t smem, const char *what) {
   static std::atomic<bool> granted[kMaxDevices];      // zero-initialised
@@ -1037,6 +1594,13 @@ int reserve_lds(size_t smem, const char *what) {
 }
 
 }  // namespace
+
+#ifdef UNFLOW_TUNE_STAMPS
+extern "C" int unflow_debug_read_stamps(void *dst, size_t bytes) {
+  const size_t n = sizeof(g_stamps) < bytes ? sizeof(g_stamps) : bytes;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 bool corr_mfma_supported(const CorrGeometry &g, int C) {
   // buffer descriptors address one image pair with 32-bit offsets
@@ -1105,6 +1669,21 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
                        C, H, W, nbx, nch);                                                                          \
   } while (0)
   const bool full = (C % CWS) == 0;
+#ifdef UNFLOW_TUNE_OLD_BWD
+  if (false) {
+#else
+  if (wide && full) {
+#endif
+    // second-generation kernel: persistent workgroups, one per CU, walking the items
+    const int nitems = (int)grid.x;
+    const int nwg = nitems < num_cus() ? nitems : num_cus();
+    const size_t smem2 = sizeof(float) * b2::LDS_FLOATS;
+    if (int rc = reserve_lds<corr_mfma_bwd2_kernel<false>>(smem2, "correlation_bwd (mfma)")) return rc;
+    if (int rc = reserve_lds<corr_mfma_bwd2_kernel<true>>(smem2, "correlation_bwd (mfma)")) return rc;
+    hipLaunchKernelGGL(corr_mfma_bwd2_kernel<false>, dim3(nwg), dim3(NTHREADS), smem2, s, topdiff, in1, g0, C, H, W, nbx, nch, nitems);
+    hipLaunchKernelGGL(corr_mfma_bwd2_kernel<true>, dim3(nwg), dim3(NTHREADS), smem2, s, topdiff, in0, g1, C, H, W, nbx, nch, nitems);
+    return launch_status("correlation_bwd (mfma)");
+  }
   if (wide && full) UNFLOW_LAUNCH(4, 4, true);
   else if (wide) UNFLOW_LAUNCH(4, 4, false);
   else UNFLOW_LAUNCH(1, 1, false);

@@ -178,8 +178,11 @@ __global__ __launch_bounds__(kBlock) void resize_area_fwd_kernel(const float *__
     r /= ow;
     const int y = (int)(r % oh);
     const long long b = r / oh;
-    const float in_y = (float)y * sy, in_y1 = (float)(y + 1) * sy;
-    const float in_x = (float)x * sx, in_x1 = (float)(x + 1) * sx;
+    // box edges are ROUNDED products (TF stores them in floats): without mul_rn the compiler
+    // contracts them into the weight subtractions as FMAs and the edge weights move by an ulp of
+    // the coordinate (1e-6 of the result)
+    const float in_y = mul_rn((float)y, sy), in_y1 = mul_rn((float)(y + 1), sy);
+    const float in_x = mul_rn((float)x, sx), in_x1 = mul_rn((float)(x + 1), sx);
     const int y0 = (int)floorf(in_y), y1 = (int)ceilf(in_y1);
     const int x0 = (int)floorf(in_x), x1 = (int)ceilf(in_x1);
     float sum = 0.f;
