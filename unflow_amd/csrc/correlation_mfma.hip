@@ -755,6 +755,8 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * 2 * (STAMP_ROWS + 1) * STA
 #define UNFLOW_STAMP(ROW, WHICH) do {} while (0)
 #endif
 
+// First-generation row sweep: kept for fp16 storage, C % 128 != 0 and rows that are not 16-byte
+// aligned (the float32 FlowNetC shape runs corr_mfma_bwd2_kernel below).
 template <int VA, int VT, bool WRT1, bool FULL, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
     const std::conditional_t<F16, _Float16, float> *__restrict__ topdiff,
@@ -781,10 +783,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
   constexpr int T_PER_WAVE = (T_PIECES + NWAVES - 1) / NWAVES;
   // the DMA of the next row is issued during the first DSL K-steps of this row,
   // so that it has the remaining K-steps to land before the barrier
-#ifndef UNFLOW_TUNE_DSL
-#define UNFLOW_TUNE_DSL 3
-#endif
-  constexpr int DSL = (VA == 4 && VT == 4) ? UNFLOW_TUNE_DSL : KSTEPS;
+  constexpr int DSL = (VA == 4 && VT == 4) ? 3 : KSTEPS;
   constexpr int APS = (A_PER_WAVE + DSL - 1) / DSL;   // A pieces issued per K-step
   constexpr int TPS = (T_PER_WAVE + DSL - 1) / DSL;   // top pieces issued per K-step
 
@@ -926,94 +925,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
   };
 
   // Tile t = 2u + ph of this wave's parity lives in ring slot u % 3 while
-  // 4t - 10 <= w <= 4t + 13, i.e. 8u <= v <= 8u + 23 with v = w - 4 ph + 10: the live tiles of
-  // row w are u_hi, u_hi - 1, u_hi - 2 with u_hi = v >> 3 (those that exist).  Everything a row
-  // needs besides its data -- the live tile of each ring slot and, per lane, the row of the top
-  // image that pairs (w, this lane's output row) -- is computed one row AHEAD, among the MFMAs of
-  // the last K-step: measured with cycle stamps, this scalar work cost 1000-1100 cycles at the top
-  // of every row with BOTH waves of a SIMD in it, i.e. with the matrix pipe idle.
-  struct RowState {
-    int tile[RING], b_row[RING];
-    bool b_rowok[RING];
+  // 4t - 10 <= w <= 4t + 13.
+  auto tile_in_slot = [&](int slot, int w) -> int {
+    const int u_hi = (w - 4 * ph + R) / 8;     // >= 0 because w >= 0 and ph <= 1
+    const int back = ((u_hi - slot) % RING + RING) % RING;
+    const int u = u_hi - back;
+    const int t = 2 * u + ph;
+    return (u >= 0 && t < ntiles && w <= 4 * t + TP - 1 + R) ? t : -1;
   };
-  auto row_state = [&](int w) __attribute__((always_inline)) {
-    RowState rs;
-    const int v = w - 4 * ph + R;                // >= 0
-    const int u_hi = v >> 3, r3 = u_hi % RING;
-#pragma unroll
-    for (int sl = 0; sl < RING; ++sl) {
-      const int back = r3 - sl + (r3 < sl ? RING : 0);
-      const int u = u_hi - back;
-      const int t = 2 * u + ph;
-      rs.tile[sl] = (u >= 0 && t < ntiles) ? t : -1;
-      const int orow = 4 * rs.tile[sl] + oyl - w + R;
-      rs.b_rowok[sl] = rs.tile[sl] >= 0 && orow >= 0 && orow <= 2 * R;
-      rs.b_row[sl] = min(max(orow, 0), 2 * R) * (GW * RW);
-    }
-    return rs;
-  };
-
-  // ---- epilogue.  A finished tile is regrouped through LDS (`ob`: [channel][row 4][16 columns])
-  // by the waves that own it and stored as 64-byte row segments by all threads.  In the steady
-  // state both halves ride inside the K-steps of the FOLLOWING rows, a few instructions per
-  // K-step, with the row barriers that exist anyway between them:
-  //   after the barrier of row w    owners write the tile's accumulators to ob and clear them, while
-  //                                 their SIMD partners (the other tile parity) already compute row w+1
-  //   K-steps of row w+2            all threads store ob (one float4 per thread in K-steps 0..3),
-  //                                 the barrier of row w+1 standing between the two halves
-  // Tiles finish 4 rows apart, so ob is free again before the next tile needs it.  Tiles that
-  // finish too close to the last row (and those that finish ON it: all that are still live) take
-  // the synchronous path: dump, barrier, store, barrier.
-  float *const ob = lds + 2 * SW_STAGE;
-  const float inv_c = 1.f / (float)C;
-  const bool pow2_c = (C & (C - 1)) == 0;
-  // thread -> (channel, tile row, 4-column group) of its q-th float4 of the image: idx = tid + 512 q
-  const int st_c4 = threadIdx.x & 3, st_rr = (threadIdx.x >> 2) & 3, st_cl = threadIdx.x >> 4;   // + 32 q channels
-  auto store_piece = [&](int t, int q) __attribute__((always_inline)) {
-    const int idx = (int)threadIdx.x + NTHREADS * q;
-    const int c = c0 + st_cl + (NTHREADS / 16) * q;
-    const int oy = 4 * t + st_rr;
-    const int y = S * oy + cy, x = S * xs0 + st_c4 * 4;
-    if (c < C && oy < hs && x < W) {
-      float4 v = *reinterpret_cast<const float4 *>(ob + idx * 4);
-      if (pow2_c) {
-        v.x *= inv_c; v.y *= inv_c; v.z *= inv_c; v.w *= inv_c;
-      } else {
-        v.x /= (float)C; v.y /= (float)C; v.z /= (float)C; v.w /= (float)C;
-      }
-      auto *dst = gout + (item * C + c) * plane + (long long)y * W + x;
-      if constexpr (F16) {   // W % 4 == 0 and 8-byte aligned tensors are preconditions of this variant
-        *reinterpret_cast<f16x4 *>(dst) = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-      } else if (VA == 4 && x + 3 < W && (W & 3) == 0) {   // VA == 4: the host checked 16-byte alignment of gout
-        *reinterpret_cast<float4 *>(dst) = v;
-      } else {
-        dst[0] = v.x;
-        if (x + 1 < W) dst[1] = v.y;
-        if (x + 2 < W) dst[2] = v.z;
-        if (x + 3 < W) dst[3] = v.w;
-      }
-    }
-  };
-  static_assert(SW_OUT / 4 == 4 * NTHREADS, "four float4 per thread");
-  const int dump_off = (4 * k * TP + oyl) * RW + b_col;   // + (m*16 + j) * TP * RW
-  // accumulators of ring slot SLOT -> ob, cleared (the slot's next tile starts on the next row).
-  // A macro, not a lambda: with the accumulator array captured by a lambda that selects the slot at
-  // run time the compiler keeps the whole array in scratch memory (10x slower, measured).
-#define UNFLOW_DUMP_TILE(SLOT)                                                             \
-  do {                                                                                     \
-    const int slot_ = (SLOT);                                                              \
-    _Pragma("unroll") for (int sl = 0; sl < RING; ++sl) {                                  \
-      if (sl == slot_) {                                                                   \
-        _Pragma("unroll") for (int m = 0; m < MTS; ++m) {                                  \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
-            ob[dump_off + (m * 16 + j) * TP * RW] = acc[sl][m][j]; /* scaled when stored */ \
-          acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
-        }                                                                                  \
-      }                                                                                    \
-    }                                                                                      \
-  } while (0)
-  int dump_tile = -1;          // tile written to ob after the previous row's barrier  (workgroup-uniform)
-  int store_tile = -1;         // tile whose image in ob is stored during this row    (workgroup-uniform)
 
   if constexpr (F16) {
     load_row(0);
@@ -1021,24 +940,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
   } else {
     issue_row(0, lds);
   }
-  RowState rs = row_state(0);
   __syncthreads();
-#ifdef UNFLOW_TUNE_STAMPS
-  // blocks 0..3 (first round) and 4 blocks of a later round, waves 0 and 4 (SIMD partners), WRT1 launch only
-  int stamp_slot = -1;
-  {
-    const int bsel = (int)blockIdx.x < 4 ? (int)blockIdx.x : ((int)blockIdx.x >= 600 && (int)blockIdx.x < 604 ? (int)blockIdx.x - 596 : -1);
-    if (WRT1 && bsel >= 0 && (wave == 0 || wave == 4)) stamp_slot = bsel * 2 + (wave >> 2);
-  }
-  UNFLOW_STAMP(STAMP_ROWS, 0);     // end of the prologue
-#endif
   for (int w = 0; w < hs; ++w) {
-    UNFLOW_STAMP(w, 0);            // top of the row (after the previous barrier / epilogue)
     const float *cur = lds + (w & 1) * SW_STAGE;
     float *nxt = lds + ((w + 1) & 1) * SW_STAGE;
     const bool more = w + 1 < hs;
     if (F16 && more) load_row(w + 1);
-    RowState rn;                   // state of row w + 1, produced in the last K-step
+    // per ring slot: live tile, LDS row offset of the top image row that pairs
+    // (w, this lane's output row), validity
+    int tile[RING], b_row[RING];
+    bool b_rowok[RING];
+#pragma unroll
+    for (int sl = 0; sl < RING; ++sl) {
+      tile[sl] = tile_in_slot(sl, w);
+      const int orow = 4 * tile[sl] + oyl - w + R;
+      b_rowok[sl] = tile[sl] >= 0 && orow >= 0 && orow <= 2 * R;
+      b_row[sl] = min(max(orow, 0), 2 * R) * (GW * RW);
+    }
 
     // A and B fragments are read one K-step ahead (two register sets), so the
     // LDS latency of step s+1 hides behind the MFMAs of step s.
@@ -1049,7 +967,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
 #pragma unroll
       for (int m = 0; m < MTS; ++m) abuf[s4 & 1][m] = ap[m * 16 * ACS];
 #pragma unroll
-      for (int sl = 0; sl < RING; ++sl) bbuf[s4 & 1][sl] = cur[rs.b_row[sl] + b_dx[s4]];   // masked at use
+      for (int sl = 0; sl < RING; ++sl) bbuf[s4 & 1][sl] = cur[b_row[sl] + b_dx[s4]];   // masked at use
     };
     auto kstep = [&](auto S4) {
       constexpr int s4 = decltype(S4)::value;
@@ -1057,79 +975,81 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
       const bool dxok = b_dxok & (1u << s4);
 #pragma unroll
       for (int sl = 0; sl < RING; ++sl) {
-        if (rs.tile[sl] >= 0) {                    // wave-uniform
-          const float b = (dxok && rs.b_rowok[sl]) ? bbuf[s4 & 1][sl] : 0.f;
+        if (tile[sl] >= 0) {                       // wave-uniform
+          const float b = (dxok && b_rowok[sl]) ? bbuf[s4 & 1][sl] : 0.f;
 #pragma unroll
           for (int m = 0; m < MTS; ++m)
             if (FULL || m < nmt)
               acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[s4 & 1][m], b, acc[sl][m], 0, 0, 0);
         }
-        // rider: a slice of the pending tile store behind a group of MFMAs
-        if (sl == 1 && s4 < 4 && store_tile >= 0) store_piece(store_tile, s4);
       }
-#ifndef UNFLOW_TUNE_NODMA
       if (!F16 && more) issue_slice(S4, w + 1, nxt);
-#endif
-      if constexpr (s4 == KSTEPS - 1) rn = row_state(w + 1);
       __builtin_amdgcn_sched_barrier(0);
     };
     load_ab(Int<0>{});
-    UNFLOW_STAMP(w, 1);            // setup done, first fragments requested
     kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
     if (F16 && more) store_row(nxt);
-    UNFLOW_STAMP(w, 2);            // K-steps issued
     __syncthreads();
-    UNFLOW_STAMP(w, 3);            // through the barrier
 
-    // ---- epilogue pipeline (see above); everything here is workgroup-uniform control
-    store_tile = dump_tile;        // written to ob during this row: stored during the next one
-    dump_tile = -1;
-    rs = rn;
-#ifdef UNFLOW_TUNE_NOSTORE
-    if (C > 0) { store_tile = -1; continue; }      // diagnostic: always true at run time, opaque to the compiler
-#endif
-    if (more) {
-      // at most one tile ends on a row that is not the last: 4 t + 13 == w
-      const int t = (w - (TP - 1 + R)) >> 2;
-      if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
-        if (w + 2 <= hs - 1) {                     // room for the two riding rows
-          if ((t & 1) == ph) UNFLOW_DUMP_TILE((t >> 1) % RING);
-          dump_tile = t;
-        } else {                                   // too close to the end: synchronous
-          if (store_tile >= 0) {                   // (cannot happen with finishing rows 4 apart; kept for safety)
+    // ---- tiles whose last window row was w: regroup through LDS to
+    // [channel][row 4][16 columns] and store 64-byte row segments.
+    const int t_lo = max(0, (w - R) / TP);         // first tile that can still be live
+    for (int t = t_lo; t < ntiles && 4 * t - R <= w; ++t) {
+      const int fin_row = min(hs - 1, 4 * t + TP - 1 + R);
+      if (fin_row != w) continue;                  // uniform over the workgroup
+      float *ob = lds + 2 * SW_STAGE;
+      const float inv = 1.f / (float)C;
+      const bool pow2 = (C & (C - 1)) == 0;
+      if ((t & 1) == ph) {
+        const int slot = (t >> 1) % RING;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
-            store_tile = -1;
-            __syncthreads();
+        for (int sl = 0; sl < RING; ++sl) {
+          if (sl == slot) {
+#pragma unroll
+            for (int m = 0; m < MTS; ++m) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const int cl = m * 16 + 4 * k + j;
+                const float v = acc[sl][m][j];
+                ob[(cl * TP + oyl) * RW + b_col] = v;      // scaled by 1/C when the image is stored
+                acc[sl][m][j] = 0.f;
+              }
+            }
           }
-          if ((t & 1) == ph) UNFLOW_DUMP_TILE((t >> 1) % RING);
-          __syncthreads();
-#pragma unroll
-          for (int q = 0; q < 4; ++q) store_piece(t, q);
-          __syncthreads();
         }
       }
-    } else {
-      // last row: flush the pipeline, then every tile that is still live ends here
-      if (store_tile >= 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
-        store_tile = -1;
-        __syncthreads();
+      __syncthreads();
+      for (int idx = threadIdx.x; idx < SW_OUT / 4; idx += NTHREADS) {
+        const int c4 = idx % (RW / 4);
+        const int rr = (idx / (RW / 4)) % TP;
+        const int cl = idx / (RW / 4 * TP);
+        const int c = c0 + cl;
+        const int oy = 4 * t + rr;
+        const int y = S * oy + cy, x = S * xs0 + c4 * 4;
+        if (c >= C || oy >= hs || x >= W) continue;
+        float4 v = *reinterpret_cast<const float4 *>(ob + idx * 4);
+        if (pow2) {
+          v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv;
+        } else {
+          v.x /= (float)C; v.y /= (float)C; v.z /= (float)C; v.w /= (float)C;
+        }
+        auto *dst = gout + (item * C + c) * plane + (long long)y * W + x;
+        if constexpr (F16) {   // W % 4 == 0 and 8-byte aligned tensors are preconditions of this variant
+          *reinterpret_cast<f16x4 *>(dst) = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        } else if (VA == 4 && x + 3 < W && (W & 3) == 0) {   // VA == 4: the host checked 16-byte alignment of gout
+          *reinterpret_cast<float4 *>(dst) = v;
+        } else {
+          dst[0] = v.x;
+          if (x + 1 < W) dst[1] = v.y;
+          if (x + 2 < W) dst[2] = v.z;
+          if (x + 3 < W) dst[3] = v.w;
+        }
       }
-      const int t_first = max(0, (w - (TP - 1 + R) + 3) >> 2);       // first t with 4 t + 13 >= w
-      for (int t = t_first; t < ntiles; ++t) {
-        if ((t & 1) == ph) UNFLOW_DUMP_TILE((t >> 1) % RING);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) store_piece(t, q);
-        __syncthreads();
-      }
+      __syncthreads();
     }
   }
 }
 
-#undef UNFLOW_DUMP_TILE
 
 // ===========================================================================
 // Backward, second generation (f32, 16-byte aligned rows, C % 128 == 0): the same row sweep

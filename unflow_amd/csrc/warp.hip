@@ -268,6 +268,265 @@ __global__ __launch_bounds__(kBlock) void image_warp_bwd_kernel(const float *__r
   }
 }
 
+// ---------------------------------------------------------------------------
+// Fast paths of the four HBM-bound gathers for C = 1, 2, 3 (the reference's uses: images and
+// flows).  The grid-stride kernels above hold ONE pixel per lane: a flow load, a wait, four tap
+// loads, a wait, a store -- two dependent memory latencies per 32..40 bytes, and 64-bit tile
+// arithmetic per pixel.  Here a 256-thread block owns a 64 x 16 pixel tile and every lane FOUR
+// pixels of one column (rows y, y+4, y+8, y+12): the four flows are loaded together, then all
+// sixteen taps, then the four results are stored -- four times the bytes in flight per wave, and
+// the item / tile decomposition is done once per block in 32-bit arithmetic.  Arithmetic per
+// pixel is the same expression as above (bit-identical results).
+// ---------------------------------------------------------------------------
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ inline float2 nt_load2(const float2 *p) {
+  const f32x2_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x2_t *>(p));
+  return make_float2(v.x, v.y);
+}
+__device__ inline void nt_store2(float2 v, float2 *p) {
+  __builtin_nontemporal_store(f32x2_t{v.x, v.y}, reinterpret_cast<f32x2_t *>(p));
+}
+// one pixel (C floats, 4-byte aligned) as ONE non-temporal vector access
+template <int C>
+__device__ inline void nt_store_px(const float (&r)[C], float *p) {
+  typedef float vec_t __attribute__((ext_vector_type(C == 3 ? 3 : (C == 2 ? 2 : 1)), aligned(4)));
+  if constexpr (C == 1) __builtin_nontemporal_store(r[0], p);
+  else if constexpr (C == 2) __builtin_nontemporal_store(vec_t{r[0], r[1]}, reinterpret_cast<vec_t *>(p));
+  else __builtin_nontemporal_store(vec_t{r[0], r[1], r[2]}, reinterpret_cast<vec_t *>(p));
+}
+template <int C>
+__device__ inline void nt_load_px(float (&r)[C], const float *p) {
+  typedef float vec_t __attribute__((ext_vector_type(C == 3 ? 3 : (C == 2 ? 2 : 1)), aligned(4)));
+  if constexpr (C == 1) {
+    r[0] = __builtin_nontemporal_load(p);
+  } else {
+    const vec_t v = __builtin_nontemporal_load(reinterpret_cast<const vec_t *>(p));
+#pragma unroll
+    for (int c = 0; c < C; ++c) r[c] = v[c];
+  }
+}
+#ifndef UNFLOW_TUNE_PPL
+#define UNFLOW_TUNE_PPL 2   // measured at B=32 384x1280 C=3: 1 -> 5.3, 2 -> 5.9, 4 -> 5.8, 8 -> 1.8 TB/s (backward_warp)
+#endif
+constexpr int kPPL = UNFLOW_TUNE_PPL;            // pixels per lane
+constexpr int kFastTileH = kTileH * kPPL;        // 16 rows
+struct FastTile {
+  int x, y0;          // lane's column, first row (rows y0 + 4 i)
+  long long item_px;  // b * H * W
+  bool xok;
+};
+__device__ inline FastTile fast_tile(int H, int W, int ntx, int nty) {
+  const int tile = blockIdx.x;
+  const int tx = tile % ntx, ty = (tile / ntx) % nty, b = tile / (ntx * nty);
+  FastTile t;
+  t.x = tx * kTileW + (threadIdx.x & (kTileW - 1));
+  t.y0 = ty * kFastTileH + (threadIdx.x >> 6);
+  t.item_px = (long long)b * H * W;
+  t.xok = t.x < W;
+  return t;
+}
+inline bool fast_ok(int B, int H, int W, int C) {
+#ifdef UNFLOW_TUNE_NOFAST
+  return false;
+#endif
+  // 32-bit element offsets inside an item, one block per tile
+  const long long tiles = (long long)B * ((H + kFastTileH - 1) / kFastTileH) * ((W + kTileW - 1) / kTileW);
+  return C >= 1 && C <= 3 && (long long)H * W * 3 < (1LL << 30) && tiles < (1LL << 31) && tiles > 0;
+}
+
+template <int C, bool CLAMP>   // CLAMP: image_warp (floor the flow, clamped taps); else backward_warp (zero outside)
+__global__ __launch_bounds__(kBlock) void warp_fwd_fast_kernel(const float *__restrict__ images,
+                                                               const float2 *__restrict__ flows,
+                                                               float *__restrict__ output, int H, int W, int ntx,
+                                                               int nty) {
+  const FastTile ft = fast_tile(H, W, ntx, nty);
+  const float *base = images + ft.item_px * C;
+  const float2 *fl = flows + ft.item_px;
+  float *out = output + ft.item_px * C;
+  bool ok[kPPL];
+  unsigned pix[kPPL];
+  float2 f[kPPL];
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) {
+    const int y = ft.y0 + kTileH * i;
+    ok[i] = ft.xok && y < H;
+    pix[i] = (unsigned)(min(y, H - 1) * W + min(ft.x, W - 1));     // clamped: always a valid address
+    f[i] = nt_load2(fl + pix[i]);
+  }
+  unsigned o00[kPPL], o01[kPPL], o10[kPPL], o11[kPPL];
+  float w00[kPPL], w01[kPPL], w10[kPPL], w11[kPPL];
+  bool in00[kPPL], in01[kPPL], in10[kPPL], in11[kPPL];
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) {
+    const int y = min(ft.y0 + kTileH * i, H - 1), x = min(ft.x, W - 1);
+    if constexpr (CLAMP) {
+      const ClampTaps t = clamp_taps(x, y, f[i], H, W);
+      o00[i] = (unsigned)t.ia * C; o10[i] = (unsigned)t.ib * C; o01[i] = (unsigned)t.ic * C; o11[i] = (unsigned)t.id * C;
+      // separately rounded products combined by add_n (image_warp.py:41-44,73)
+      w00[i] = (1.f - t.xw) * (1.f - t.yw);   // wa
+      w10[i] = (1.f - t.xw) * t.yw;           // wb
+      w01[i] = t.xw * (1.f - t.yw);           // wc
+      w11[i] = t.xw * t.yw;                   // wd
+      in00[i] = in01[i] = in10[i] = in11[i] = true;
+    } else {
+      const Taps t = position_taps(x, y, f[i]);
+      const bool in_x0 = t.x0 >= 0 && t.x0 < W, in_x1 = t.x1 >= 0 && t.x1 < W;
+      const bool in_y0 = t.y0 >= 0 && t.y0 < H, in_y1 = t.y1 >= 0 && t.y1 < H;
+      const int xc0 = min(max(t.x0, 0), W - 1), xc1 = min(max(t.x1, 0), W - 1);
+      const int yc0 = min(max(t.y0, 0), H - 1), yc1 = min(max(t.y1, 0), H - 1);
+      o00[i] = (unsigned)(yc0 * W + xc0) * C; o01[i] = (unsigned)(yc0 * W + xc1) * C;
+      o10[i] = (unsigned)(yc1 * W + xc0) * C; o11[i] = (unsigned)(yc1 * W + xc1) * C;
+      in00[i] = in_x0 && in_y0; in01[i] = in_x1 && in_y0; in10[i] = in_x0 && in_y1; in11[i] = in_x1 && in_y1;
+      w00[i] = t.w_left * t.w_top; w01[i] = t.w_right * t.w_top;
+      w10[i] = t.w_left * t.w_bottom; w11[i] = t.w_right * t.w_bottom;
+    }
+  }
+  float l00[kPPL][C], l01[kPPL][C], l10[kPPL][C], l11[kPPL][C];
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) {
+    // pointers first, constant channel index after: the C loads of a tap merge into one dwordx2 / x3
+    const float *p00 = base + o00[i], *p01 = base + o01[i], *p10 = base + o10[i], *p11 = base + o11[i];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      l00[i][c] = p00[c];
+      l01[i][c] = p01[c];
+      l10[i][c] = p10[c];
+      l11[i][c] = p11[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      pin(l00[i][c]); pin(l01[i][c]); pin(l10[i][c]); pin(l11[i][c]);
+    }
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) {
+    float r[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if constexpr (CLAMP) {
+        float s = mul_rn(w00[i], l00[i][c]);
+        s = add_rn(s, mul_rn(w10[i], l10[i][c]));
+        s = add_rn(s, mul_rn(w01[i], l01[i][c]));
+        s = add_rn(s, mul_rn(w11[i], l11[i][c]));
+        r[c] = s;
+      } else {
+        float sum = fmaf(w00[i], in00[i] ? l00[i][c] : 0.f, 0.f);
+        sum = fmaf(w01[i], in01[i] ? l01[i][c] : 0.f, sum);
+        sum = fmaf(w10[i], in10[i] ? l10[i][c] : 0.f, sum);
+        sum = fmaf(w11[i], in11[i] ? l11[i][c] : 0.f, sum);
+        r[c] = sum;
+      }
+    }
+    if (ok[i]) nt_store_px<C>(r, out + (size_t)pix[i] * C);
+  }
+}
+
+template <int C, bool CLAMP>   // gradient with respect to the flow
+__global__ __launch_bounds__(kBlock) void warp_bwd_flow_fast_kernel(const float *__restrict__ grad,
+                                                                    const float *__restrict__ images,
+                                                                    const float2 *__restrict__ flows,
+                                                                    float2 *__restrict__ d_flow, int H, int W, int ntx,
+                                                                    int nty) {
+  const FastTile ft = fast_tile(H, W, ntx, nty);
+  const float *base = images + ft.item_px * C;
+  const float *gin = grad + ft.item_px * C;
+  const float2 *fl = flows + ft.item_px;
+  float2 *dout = d_flow + ft.item_px;
+  bool ok[kPPL];
+  unsigned pix[kPPL];
+  float2 f[kPPL];
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) {
+    const int y = ft.y0 + kTileH * i;
+    ok[i] = ft.xok && y < H;
+    pix[i] = (unsigned)(min(y, H - 1) * W + min(ft.x, W - 1));
+    f[i] = nt_load2(fl + pix[i]);
+  }
+  unsigned o00[kPPL], o01[kPPL], o10[kPPL], o11[kPPL];
+  bool in00[kPPL], in01[kPPL], in10[kPPL], in11[kPPL];
+  float wx[kPPL][2], wy[kPPL][2];      // CLAMP: (xw, yw) fractions; else (w_left, w_right), (w_top, w_bottom)
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) {
+    const int y = min(ft.y0 + kTileH * i, H - 1), x = min(ft.x, W - 1);
+    if constexpr (CLAMP) {
+      const ClampTaps t = clamp_taps(x, y, f[i], H, W);
+      o00[i] = (unsigned)t.ia * C; o10[i] = (unsigned)t.ib * C; o01[i] = (unsigned)t.ic * C; o11[i] = (unsigned)t.id * C;
+      wx[i][0] = t.xw; wy[i][0] = t.yw; wx[i][1] = 0.f; wy[i][1] = 0.f;
+      in00[i] = in01[i] = in10[i] = in11[i] = true;
+    } else {
+      const Taps t = position_taps(x, y, f[i]);
+      const bool in_x0 = t.x0 >= 0 && t.x0 < W, in_x1 = t.x1 >= 0 && t.x1 < W;
+      const bool in_y0 = t.y0 >= 0 && t.y0 < H, in_y1 = t.y1 >= 0 && t.y1 < H;
+      const int xc0 = min(max(t.x0, 0), W - 1), xc1 = min(max(t.x1, 0), W - 1);
+      const int yc0 = min(max(t.y0, 0), H - 1), yc1 = min(max(t.y1, 0), H - 1);
+      o00[i] = (unsigned)(yc0 * W + xc0) * C; o01[i] = (unsigned)(yc0 * W + xc1) * C;
+      o10[i] = (unsigned)(yc1 * W + xc0) * C; o11[i] = (unsigned)(yc1 * W + xc1) * C;
+      in00[i] = in_x0 && in_y0; in01[i] = in_x1 && in_y0; in10[i] = in_x0 && in_y1; in11[i] = in_x1 && in_y1;
+      wx[i][0] = t.w_left; wx[i][1] = t.w_right; wy[i][0] = t.w_top; wy[i][1] = t.w_bottom;
+    }
+  }
+  float l00[kPPL][C], l01[kPPL][C], l10[kPPL][C], l11[kPPL][C], g[kPPL][C];
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) {
+    // pointers first, constant channel index after: the C loads of a tap merge into one dwordx2 / x3
+    const float *p00 = base + o00[i], *p01 = base + o01[i], *p10 = base + o10[i], *p11 = base + o11[i];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      l00[i][c] = p00[c];
+      l01[i][c] = p01[c];
+      l10[i][c] = p10[c];
+      l11[i][c] = p11[c];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) nt_load_px<C>(g[i], gin + (size_t)pix[i] * C);
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      pin(l00[i][c]); pin(l01[i][c]); pin(l10[i][c]); pin(l11[i][c]);
+    }
+#pragma unroll
+  for (int i = 0; i < kPPL; ++i) {
+    float2 d;
+    if constexpr (CLAMP) {
+      // taps a = (y0,x0), b = (y1,x0), c = (y0,x1), d = (y1,x1)   (image_warp_bwd_kernel)
+      float ga = 0.f, gb = 0.f, gc = 0.f, gd = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        ga = fmaf(g[i][c], l00[i][c], ga);
+        gb = fmaf(g[i][c], l10[i][c], gb);
+        gc = fmaf(g[i][c], l01[i][c], gc);
+        gd = fmaf(g[i][c], l11[i][c], gd);
+      }
+      const float xw = wx[i][0], yw = wy[i][0];
+      d.x = (gc - ga) * (1.f - yw) + (gd - gb) * yw;
+      d.y = (gb - ga) * (1.f - xw) + (gd - gc) * xw;
+    } else {
+      float du = 0.f, dv = 0.f;
+      const float w_left = wx[i][0], w_right = wx[i][1], w_top = wy[i][0], w_bottom = wy[i][1];
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        // masked products: an outside tap adds fmaf(w, 0, d) == d exactly   (backward_warp_bwd_kernel)
+        const float q00 = (in00[i] ? l00[i][c] : 0.f) * g[i][c], q01 = (in01[i] ? l01[i][c] : 0.f) * g[i][c];
+        const float q10 = (in10[i] ? l10[i][c] : 0.f) * g[i][c], q11 = (in11[i] ? l11[i][c] : 0.f) * g[i][c];
+        du = fmaf(-w_top, q00, du);
+        dv = fmaf(-w_left, q00, dv);
+        du = fmaf(w_top, q01, du);
+        dv = fmaf(-w_right, q01, dv);
+        du = fmaf(-w_bottom, q10, du);
+        dv = fmaf(w_left, q10, dv);
+        du = fmaf(w_bottom, q11, du);
+        dv = fmaf(w_right, q11, dv);
+      }
+      d = make_float2(du, dv);
+    }
+    if (ok[i]) nt_store2(d, dout + pix[i]);
+  }
+}
+
 // ForwardWarp window (ops/forward_warp_op.cu.cc:38-51): k = ceil(dist+2) = 4.
 struct Window {
   float tx, ty;
@@ -611,33 +870,38 @@ __global__ __launch_bounds__(kBlock) void downsample_kernel(const float *__restr
 // Image gradient of image_warp (the scatter-add TF derives from tf.gather), LDS-privatised.
 // One workgroup owns a 64x16 tile of pixels; the cells its 2x2 taps touch form a bounding
 // box that -- for a coherent flow -- is little larger than the tile.  The taps are added
-// into an LDS window of that box with a compare-and-swap float add (ds_add_f32 retires a
-// lane per ~3 cycles on gfx950, profiles/ubench_lds_atomic.txt; a CAS round is an order of
-// magnitude cheaper at the low same-address contention of a warp), and the window is
-// flushed with global atomics over CONTIGUOUS rows of ww*C floats -- instead of 4*C strided
-// global atomics per pixel.  Tiles whose box does not fit fall back to those.
-__device__ inline void lds_add_f32(float *addr, float v) {
-  unsigned *ua = reinterpret_cast<unsigned *>(addr);
-  unsigned old = *ua, assumed;
-  do {
-    assumed = old;
-    old = atomicCAS(ua, assumed, __float_as_uint(__uint_as_float(assumed) + v));
-  } while (old != assumed);
-}
-
-template <int C>
-__global__ __launch_bounds__(kSplatThreads) void image_warp_bwd_im_tiled_kernel(const float *__restrict__ grad,
+// into an LDS window of that box and the window is flushed with global atomics over
+// CONTIGUOUS rows of ww*C floats -- instead of 4*C strided global atomics per pixel.  Tiles
+// whose box does not fit fall back to those.
+// LDS float atomics retire a lane per ~3 cycles on gfx950 (ds_add_f32 and a compare-and-swap
+// loop alike: 12 adds per pixel made this kernel 1.0 ms at 32 x 384 x 1280 x 3), integer LDS
+// atomics 64 lanes per 5 cycles.  So the window accumulates in FIXED POINT with a scale chosen per
+// tile from the largest |grad| of its pixels: a value v becomes two 32-bit integers,
+//   hi = rint(v * S1),  lo = rint((v - hi / S1) * S1 * 2^19),   S1 = 2^18 / gmax  (a power of two),
+// added to two integer windows.  |hi| <= 2^18 and |lo| <= 2^18 per add and a window cell receives at
+// most 4 * 1024 adds, so neither sum leaves 32 bits; a contribution is represented to 2^-38 of the
+// tile's largest gradient (f32 itself resolves 2^-24 of a value) and integer addition makes the
+// window sum independent of the order of the adds.
+// TY: rows of the pixel tile (64 x TY, one lane per pixel).  Three channels take 64 x 8 tiles: the box of a
+// 64 x 16 tile (1.5 .. 2 thousand pixels at the flow gradients of the KITTI-shaped workload) times three
+// channels times two integer windows does not fit the 60 KB.
+template <int C, int TY>
+__global__ __launch_bounds__(kSX * TY) void image_warp_bwd_im_tiled_kernel(const float *__restrict__ grad,
                                                                                 const float2 *__restrict__ flow,
                                                                                 float *__restrict__ d_im, int H,
                                                                                 int W) {
-  __shared__ float win[kWinCells];
+  __shared__ int win[kWinCells];               // [hi window | lo window], kWinCells / 2 cells each
   __shared__ int box[4];
-  const int x0 = blockIdx.x * kSX, y0 = blockIdx.y * kSY;
+  __shared__ unsigned gmax_bits;
+  constexpr int kCells = kWinCells / 2;
+  constexpr int NT = kSX * TY;
+  const int x0 = blockIdx.x * kSX, y0 = blockIdx.y * TY;
   const long long item = (long long)blockIdx.z * H * W;
   const int sx = x0 + (threadIdx.x % kSX), sy = y0 + threadIdx.x / kSX;
   const bool live = sx < W && sy < H;
   int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
   float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f, g[C];
+  float gabs = 0.f;
   if (live) {
     const long long p = item + (long long)sy * W + sx;
     const ClampTaps t = clamp_taps(sx, sy, flow[p], H, W);
@@ -646,25 +910,36 @@ __global__ __launch_bounds__(kSplatThreads) void image_warp_bwd_im_tiled_kernel(
     wa = (1.f - t.xw) * (1.f - t.yw); wb = (1.f - t.xw) * t.yw;
     wc = t.xw * (1.f - t.yw); wd = t.xw * t.yw;
 #pragma unroll
-    for (int c = 0; c < C; ++c) g[c] = grad[p * C + c];
+    for (int c = 0; c < C; ++c) {
+      g[c] = grad[p * C + c];
+      gabs = fmaxf(gabs, fabsf(g[c]));
+    }
   }
   if (threadIdx.x < 4) box[threadIdx.x] = 0x7fffffff;
+  if (threadIdx.x == 0) gmax_bits = 0u;
   __syncthreads();
   {
     int b0 = live ? tx0 : 0x7fffffff, b1 = live ? ty0 : 0x7fffffff;
     int b2 = live ? -tx1 : 0x7fffffff, b3 = live ? -ty1 : 0x7fffffff;
+    // NaN / inf gradients: the tile takes the float path below (fmaxf drops a NaN, so test it apart)
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) bad = bad || (live && !(fabsf(g[c]) <= 3.0e38f));
+    unsigned gb = bad ? 0x7f800000u : __float_as_uint(gabs);      // non-negative floats order like their bits
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       b0 = min(b0, __shfl_xor(b0, off, 64));
       b1 = min(b1, __shfl_xor(b1, off, 64));
       b2 = min(b2, __shfl_xor(b2, off, 64));
       b3 = min(b3, __shfl_xor(b3, off, 64));
+      gb = max(gb, (unsigned)__shfl_xor((int)gb, off, 64));
     }
     if ((threadIdx.x & 63) == 0 && b0 != 0x7fffffff) {
       atomicMin(&box[0], b0);
       atomicMin(&box[1], b1);
       atomicMin(&box[2], b2);
       atomicMin(&box[3], b3);
+      atomicMax(&gmax_bits, gb);
     }
   }
   __syncthreads();
@@ -672,7 +947,13 @@ __global__ __launch_bounds__(kSplatThreads) void image_warp_bwd_im_tiled_kernel(
   const int ww = -box[2] - wx0 + 1, wh = -box[3] - wy0 + 1;
   float *base = d_im + item * C;
   if (wx0 == 0x7fffffff) return;                       // no live pixel (cannot happen for a launched tile)
-  if ((long long)ww * wh * C > kWinCells) {            // incoherent flow: the strided global atomics
+  const float gmax = __uint_as_float(gmax_bits);
+  if (gmax == 0.f) return;                             // an all-zero gradient tile adds nothing
+  // S1 = 2^(18 - e) with 2^(e-1) <= gmax < 2^e: |v * S1| <= 2^18.  Extreme exponents (S1 or its inverse
+  // not a normal float) and non-finite gradients keep the float atomics.
+  const int e = (int)((gmax_bits >> 23) & 0xff) - 126;
+  const bool fixed_ok = e > -100 && e < 100 && gmax_bits < 0x7f800000u;
+  if ((long long)ww * wh * C > kCells || !fixed_ok) {  // incoherent flow: the strided global atomics
     if (live) {
 #pragma unroll
       for (int c = 0; c < C; ++c) {
@@ -684,27 +965,39 @@ __global__ __launch_bounds__(kSplatThreads) void image_warp_bwd_im_tiled_kernel(
     }
     return;
   }
+  const float s1 = __uint_as_float((unsigned)(127 + 18 - e) << 23), inv_s1 = __uint_as_float((unsigned)(127 - 18 + e) << 23);
+  const float s2 = 524288.f;                           // 2^19: lo = residual * S1 * 2^19
   const int cells = ww * wh * C;
-  for (int i = threadIdx.x; i < cells; i += kSplatThreads) win[i] = 0.f;
+  for (int i = threadIdx.x; i < cells; i += NT) {
+    win[i] = 0;
+    win[kCells + i] = 0;
+  }
   __syncthreads();
   if (live) {
-    float *a = win + ((ty0 - wy0) * ww + (tx0 - wx0)) * C, *b = win + ((ty1 - wy0) * ww + (tx0 - wx0)) * C;
-    float *c_ = win + ((ty0 - wy0) * ww + (tx1 - wx0)) * C, *d = win + ((ty1 - wy0) * ww + (tx1 - wx0)) * C;
+    int *a = win + ((ty0 - wy0) * ww + (tx0 - wx0)) * C, *b = win + ((ty1 - wy0) * ww + (tx0 - wx0)) * C;
+    int *c_ = win + ((ty0 - wy0) * ww + (tx1 - wx0)) * C, *d = win + ((ty1 - wy0) * ww + (tx1 - wx0)) * C;
+    auto add = [&](int *cell, float v) {
+      const float hi = rintf(v * s1);                  // exact product (power of two), |hi| <= 2^18
+      const float res = fmaf(-hi, inv_s1, v);          // exact residual, |res| <= 0.5 / S1
+      atomicAdd(cell, (int)hi);
+      atomicAdd(cell + kCells, (int)rintf(res * s1 * s2));
+    };
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      lds_add_f32(a + c, wa * g[c]);
-      lds_add_f32(b + c, wb * g[c]);
-      lds_add_f32(c_ + c, wc * g[c]);
-      lds_add_f32(d + c, wd * g[c]);
+      add(a + c, wa * g[c]);
+      add(b + c, wb * g[c]);
+      add(c_ + c, wc * g[c]);
+      add(d + c, wd * g[c]);
     }
   }
   __syncthreads();
   const int rowf = ww * C;                             // one window row = rowf contiguous floats in d_im
-  for (int ly = threadIdx.x >> 6; ly < wh; ly += kSplatThreads / 64) {
+  const float inv_s12 = inv_s1 * (1.f / 524288.f);
+  for (int ly = threadIdx.x >> 6; ly < wh; ly += NT / 64) {
     float *drow = base + ((long long)(wy0 + ly) * W + wx0) * C;
     for (int i = threadIdx.x & 63; i < rowf; i += 64) {
-      const float v = win[ly * rowf + i];
-      if (v != 0.f) unsafeAtomicAdd(drow + i, v);
+      const int hi = win[ly * rowf + i], lo = win[kCells + ly * rowf + i];
+      if ((hi | lo) != 0) unsafeAtomicAdd(drow + i, fmaf((float)lo, inv_s12, (float)hi * inv_s1));
     }
   }
 }
@@ -725,6 +1018,16 @@ int check_dims(const char *op, int B, int H, int W, int C) {
 
 using namespace unflow;
 
+// the 4-pixel-per-lane kernels: one 256-thread block per 64 x 16 tile
+#define FAST_LAUNCH(KERNEL, CLAMP, ...)                                                                    \
+  do {                                                                                                     \
+    const int ntx_ = (W + kTileW - 1) / kTileW, nty_ = (H + kFastTileH - 1) / kFastTileH;                  \
+    const dim3 g_((unsigned)((long long)B * ntx_ * nty_));                                                  \
+    if (C == 1) hipLaunchKernelGGL((KERNEL<1, CLAMP>), g_, dim3(kBlock), 0, s, __VA_ARGS__, H, W, ntx_, nty_);      \
+    else if (C == 2) hipLaunchKernelGGL((KERNEL<2, CLAMP>), g_, dim3(kBlock), 0, s, __VA_ARGS__, H, W, ntx_, nty_); \
+    else hipLaunchKernelGGL((KERNEL<3, CLAMP>), g_, dim3(kBlock), 0, s, __VA_ARGS__, H, W, ntx_, nty_);             \
+  } while (0)
+
 #define DISPATCH_C(KERNEL, C, ...)                                                               \
   do {                                                                                           \
     switch (C) {                                                                                 \
@@ -742,6 +1045,10 @@ extern "C" int unflow_backward_warp_fwd(const float *images, const float *flows,
   const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0 || C == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
+  if (fast_ok(B, H, W, C)) {
+    FAST_LAUNCH(warp_fwd_fast_kernel, false, images, reinterpret_cast<const float2 *>(flows), output);
+    return launch_status("backward_warp_fwd");
+  }
   const unsigned grid = grid_for(vtotal);
   DISPATCH_C(backward_warp_fwd_kernel, C, images, reinterpret_cast<const float2 *>(flows), output, H, W, C, vtotal);
   return launch_status("backward_warp_fwd");
@@ -755,6 +1062,11 @@ extern "C" int unflow_backward_warp_bwd(const float *input_grad, const float *im
   const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
+  if (fast_ok(B, H, W, C)) {
+    FAST_LAUNCH(warp_bwd_flow_fast_kernel, false, input_grad, images, reinterpret_cast<const float2 *>(flows),
+                reinterpret_cast<float2 *>(output_grad));
+    return launch_status("backward_warp_bwd");
+  }
   const unsigned grid = grid_for(vtotal);
   DISPATCH_C(backward_warp_bwd_kernel, C, input_grad, images, reinterpret_cast<const float2 *>(flows),
              reinterpret_cast<float2 *>(output_grad), H, W, C, vtotal);
@@ -768,6 +1080,10 @@ extern "C" int unflow_image_warp_fwd(const float *im, const float *flow, float *
   const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0 || C == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
+  if (fast_ok(B, H, W, C)) {
+    FAST_LAUNCH(warp_fwd_fast_kernel, true, im, reinterpret_cast<const float2 *>(flow), warped);
+    return launch_status("image_warp_fwd");
+  }
   const unsigned grid = grid_for(vtotal);
   DISPATCH_C(image_warp_fwd_kernel, C, im, reinterpret_cast<const float2 *>(flow), warped, H, W, C, vtotal);
   return launch_status("image_warp_fwd");
@@ -797,15 +1113,21 @@ extern "C" int unflow_image_warp_bwd(const float *grad, const float *im, const f
   }
   if (d_im && C >= 1 && C <= 3 && B <= 65535) {
     // image gradient through the LDS-privatised scatter; the flow gradient (if wanted) separately
-    const dim3 tg((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B);
+    const dim3 tg((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B), tg8((W + kSX - 1) / kSX, (H + 7) / 8, B);
     const float2 *fl = reinterpret_cast<const float2 *>(flow);
-    if (C == 1) hipLaunchKernelGGL(image_warp_bwd_im_tiled_kernel<1>, tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
-    else if (C == 2) hipLaunchKernelGGL(image_warp_bwd_im_tiled_kernel<2>, tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
-    else hipLaunchKernelGGL(image_warp_bwd_im_tiled_kernel<3>, tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
-    if (d_flow) { IW_BWD_C(false, true) }
+    if (C == 1) hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<1, kSY>), tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
+    else if (C == 2) hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<2, kSY>), tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
+    else hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<3, 8>), tg8, dim3(kSX * 8), 0, s, grad, fl, d_im, H, W);
+    if (d_flow) {
+      if (fast_ok(B, H, W, C))
+        FAST_LAUNCH(warp_bwd_flow_fast_kernel, true, grad, im, fl, reinterpret_cast<float2 *>(d_flow));
+      else { IW_BWD_C(false, true) }
+    }
   } else if (d_im && d_flow) { IW_BWD_C(true, true) }
   else if (d_im) { IW_BWD_C(true, false) }
-  else { IW_BWD_C(false, true) }
+  else if (fast_ok(B, H, W, C)) {
+    FAST_LAUNCH(warp_bwd_flow_fast_kernel, true, grad, im, reinterpret_cast<const float2 *>(flow), reinterpret_cast<float2 *>(d_flow));
+  } else { IW_BWD_C(false, true) }
 #undef IW_BWD_C
 #undef IW_BWD
   return launch_status("image_warp_bwd");
