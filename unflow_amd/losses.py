@@ -113,9 +113,9 @@ def occlusion(flow_fw, flow_bw):
     return occ_fw, occ_bw
 
 
-def sym_loss(mask, density_other, norm_count=0):
+def sym_loss(mask, density_other, norm_count=0, thresh=DISOCC_THRESH):
     """One direction of ``losses['sym']`` (losses.py:60-61):
-    ``charbonnier_loss((1 - mask) - cast(density_other < DISOCC_THRESH))`` in one pass."""
+    ``charbonnier_loss((1 - mask) - cast(density_other < thresh))`` in one pass."""
     mask, density_other = _dev(mask.detach(), "mask"), _dev(density_other.detach(), "density_other")
     _require_rank4(mask, "mask")
     B, H, W, C = mask.shape
@@ -124,9 +124,29 @@ def sym_loss(mask, density_other, norm_count=0):
     loss = torch.empty((), device=mask.device, dtype=torch.float32)
     ws = _workspace(B, H, W, mask.device)
     with torch.cuda.device(mask.device):
-        _lib.check(_lib.load().unflow_sym_loss_fwd(_ptr(mask), _ptr(density_other), DISOCC_THRESH, _ptr(loss),
+        _lib.check(_lib.load().unflow_sym_loss_fwd(_ptr(mask), _ptr(density_other), float(thresh), _ptr(loss),
                                                    _ptr(ws), B, H, W, norm_count, _stream()))
     return loss
+
+
+def occ_loss(mask, norm_count=0):
+    """One direction of ``losses['occ']`` (losses.py:62-63): ``charbonnier_loss(1 - mask)`` in one
+    pass (the sym kernel with a comparison that is never true); no gradient, as in the reference
+    (the masks are stop-gradient'd)."""
+    return sym_loss(mask, mask, norm_count=norm_count, thresh=-1.0)
+
+
+class _FlowDiff(torch.autograd.Function):
+    """``flow + flow_other_warped`` (losses.py:40-41) taken from the occlusion kernel, which computes it
+    anyway; the gradient passes to both summands unchanged."""
+
+    @staticmethod
+    def forward(ctx, flow, flow_other_warped, diff):
+        return diff.view_as(diff)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, None
 
 
 # --------------------------------------------------------------------------- charbonnier
@@ -451,6 +471,17 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     ``norm_batch`` (extension) is the GLOBAL batch size when this call sees a
     shard of the batch; 0 = the local batch.  ``return_aux`` also returns the intermediate
     tensors (warped images, masks, occlusion maps)."""
+    parts, aux = compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask, mask_occlusion, data_max_distance,
+                                      norm_batch, terms, return_aux)
+    losses = {k: v[0] + v[1] for k, v in parts.items()}      # losses.py: each entry is forward + backward direction
+    return (losses, aux) if return_aux else losses
+
+
+def compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion='',
+                         data_max_distance=1, norm_batch=0, terms=None, return_aux=False):
+    """``compute_losses`` with every entry left as its (forward, backward) pair of scalars: the pyramid
+    driver folds all of them into its weighted sum with ONE fused op instead of an add and a scale
+    per term and level.  Returns (parts, aux)."""
     assert mask_occlusion in ['fb', 'disocc', '']
     losses = {}
     B, H, W, _ = im1.shape
@@ -491,8 +522,8 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     if want('fb') or return_aux:
         flow_bw_warped = image_warp(flow_bw, flow_fw)
         flow_fw_warped = image_warp(flow_fw, flow_bw)
-        _, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
-        _, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
+        diff_fw, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
+        diff_bw, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
     elif mask_occlusion == 'fb':
         src = border_mask if border_mask is not None else None
         _, fb_occ_fw = fb_occlusion_warp(flow_fw, flow_bw, mask_fw, mask_in=src)
@@ -502,39 +533,35 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
         mask_bw = mask_bw * (1 - disocc_fw)
 
     if want('sym'):
-        losses['sym'] = sym_loss(mask_fw, dens_bw, norm_count=npx) + sym_loss(mask_bw, dens_fw, norm_count=npx)
-    if want('occ') or return_aux:
-        occ_fw = 1 - mask_fw
-        occ_bw = 1 - mask_bw
-    if want('occ'):
-        losses['occ'] = (charbonnier_loss(occ_fw, norm_count=npx) +
-                         charbonnier_loss(occ_bw, norm_count=npx))
+        losses['sym'] = (sym_loss(mask_fw, dens_bw, norm_count=npx), sym_loss(mask_bw, dens_fw, norm_count=npx))
+    if want('occ'):      # charbonnier_loss(1 - mask), the complement taken inside the kernel
+        losses['occ'] = (occ_loss(mask_fw, norm_count=npx), occ_loss(mask_bw, norm_count=npx))
     if want('photo'):
-        losses['photo'] = (charbonnier_loss(im1 - im2_warped, mask_fw, beta=255, norm_count=npx * 3) +
+        losses['photo'] = (charbonnier_loss(im1 - im2_warped, mask_fw, beta=255, norm_count=npx * 3),
                            charbonnier_loss(im2 - im1_warped, mask_bw, beta=255, norm_count=npx * 3))
     if want('grad'):
-        losses['grad'] = (gradient_loss(im1, im2_warped, mask_fw, norm_count=npx * 6) +
+        losses['grad'] = (gradient_loss(im1, im2_warped, mask_fw, norm_count=npx * 6),
                           gradient_loss(im2, im1_warped, mask_bw, norm_count=npx * 6))
     if want('smooth_1st'):
-        losses['smooth_1st'] = (smoothness_loss(flow_fw, norm_count=npx * 2) +
+        losses['smooth_1st'] = (smoothness_loss(flow_fw, norm_count=npx * 2),
                                 smoothness_loss(flow_bw, norm_count=npx * 2))
     if want('smooth_2nd'):
-        losses['smooth_2nd'] = (second_order_loss(flow_fw, norm_count=npx * 4) +
+        losses['smooth_2nd'] = (second_order_loss(flow_fw, norm_count=npx * 4),
                                 second_order_loss(flow_bw, norm_count=npx * 4))
-    if want('fb'):
-        losses['fb'] = (charbonnier_loss(flow_fw + flow_bw_warped, mask_fw, norm_count=npx * 2) +
-                        charbonnier_loss(flow_bw + flow_fw_warped, mask_bw, norm_count=npx * 2))
+    if want('fb'):       # flow + warped other flow: the sum the occlusion kernel already wrote (same rounding)
+        losses['fb'] = (charbonnier_loss(_FlowDiff.apply(flow_fw, flow_bw_warped, diff_fw), mask_fw, norm_count=npx * 2),
+                        charbonnier_loss(_FlowDiff.apply(flow_bw, flow_fw_warped, diff_bw), mask_bw, norm_count=npx * 2))
     if want('ternary') and im2_warped is None:
         losses['ternary'] = (ternary_loss_warped(im1, im2, flow_fw, mask_fw, max_distance=data_max_distance,
-                                                 norm_count=npx) +
+                                                 norm_count=npx),
                              ternary_loss_warped(im2, im1, flow_bw, mask_bw, max_distance=data_max_distance,
                                                  norm_count=npx))
     elif want('ternary'):
         losses['ternary'] = (ternary_loss(im1, im2_warped, mask_fw, max_distance=data_max_distance,
-                                          norm_count=npx) +
+                                          norm_count=npx),
                              ternary_loss(im2, im1_warped, mask_bw, max_distance=data_max_distance,
                                           norm_count=npx))
     aux = dict(im2_warped=im2_warped, im1_warped=im1_warped, mask_fw=mask_fw, mask_bw=mask_bw,
                disocc_fw=disocc_fw, disocc_bw=disocc_bw, flow_bw_warped=flow_bw_warped,
                flow_fw_warped=flow_fw_warped, fb_occ_fw=fb_occ_fw, fb_occ_bw=fb_occ_bw)
-    return (losses, aux) if return_aux else losses
+    return losses, aux

@@ -7,7 +7,9 @@ The network that produces the flow pyramid (``flownet``, :72-79), augmentation
 (:30-62) and the weight-decay term (:147) are outside this path; the caller
 passes the pyramid in and adds its own regularisation loss.
 """
-from .losses import compute_losses
+import torch
+
+from .losses import compute_losses_parts
 from .util import downsample
 
 # unsupervised.py:10
@@ -45,21 +47,75 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     # TF1 only runs what the fetched scalar needs: terms without a weight are never evaluated
     weights = {name: params[name + '_weight'] for name in LOSSES if params.get(name + '_weight')}
 
-    total = 0.0
-    per_term = {name: 0.0 for name in LOSSES}
+    # flow scaling of every level (:118) as ONE multi-tensor launch (and one for its gradient)
+    scales = [top_scale / (2 ** i) for i in range(n_levels)]
+    scaled = _scale_all(scales + scales, list(flows_fw[:n_levels]) + list(flows_bw[:n_levels]))
+    scaled_fw, scaled_bw = scaled[:n_levels], scaled[n_levels:]
+
+    # The reference adds up  layer_weight * sum_k weight_k * loss_k  term by term (:134-141).  On the
+    # GPU every one of those scalar multiplies and adds is a kernel launch (about 200 of the ~400
+    # launches of the KITTI pyramid), so the per-direction scalars of all levels are collected
+    # and folded with ONE dot product; autograd hands every loss its upstream weight from there.
+    scalars, coeffs, owners = [], [], []
     for i in range(n_levels):
         layer_weight, patch_distance = levels[i]
-        scale = top_scale / (2 ** i)                                           # :118
         im1_s, im2_s, mask_s = images
-        level = compute_losses(im1_s, im2_s, flows_fw[i] * scale, flows_bw[i] * scale,
-                               border_mask=mask_s if params.get('border_mask') else None,
-                               mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
-                               norm_batch=norm_batch, terms=tuple(weights))
-        layer_loss = 0.0
+        level = compute_losses_parts(im1_s, im2_s, scaled_fw[i], scaled_bw[i],
+                                     border_mask=mask_s if params.get('border_mask') else None,
+                                     mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
+                                     norm_batch=norm_batch, terms=tuple(weights))[0]
         for name, weight in weights.items():                                   # :134-139
-            layer_loss = layer_loss + weight * level[name]
-            per_term[name] = per_term[name] + layer_weight * level[name]
-        total = total + layer_weight * layer_loss                              # :141
+            for part in level[name]:
+                scalars.append(part)
+                coeffs.append(layer_weight * weight)
+                owners.append((name, layer_weight))
         if i + 1 < n_levels:   # the reference also shrinks after the last level; that result is unused
             images = tuple(downsample(t, 2) for t in images)                   # :143-145
+    if not scalars:
+        zero = torch.zeros((), device=im1_norm.device)
+        return zero, {name: zero for name in LOSSES}
+    stacked = torch.stack(scalars)
+    coeff_t, table_t = _fold_tables(stacked.device, tuple(coeffs), tuple(owners))
+    total = torch.dot(stacked, coeff_t)                                        # :141
+    # combined_losses[k] = sum over levels of layer_weight * loss_k (:139): logging only, no gradient
+    with torch.no_grad():
+        sums = table_t @ stacked.detach()
+    per_term = {name: sums[k] for k, name in enumerate(LOSSES)}
     return total, per_term
+
+
+_FOLD_CACHE = {}
+
+
+def _fold_tables(device, coeffs, owners):
+    """Device copies of the folding coefficients, built once per configuration (a host-to-device copy
+    per call would be one more launch, and could not be captured into a HIP graph)."""
+    key = (str(device), coeffs, owners)
+    if key not in _FOLD_CACHE:
+        table = torch.zeros((len(LOSSES), len(coeffs)), dtype=torch.float32)
+        for j, (name, layer_weight) in enumerate(owners):
+            table[LOSSES.index(name), j] = layer_weight
+        _FOLD_CACHE[key] = (torch.tensor(coeffs, dtype=torch.float32).to(device), table.to(device))
+    return _FOLD_CACHE[key]
+
+
+class _ScaleAll(torch.autograd.Function):
+    """tensors[i] * scales[i] for a list of tensors of different shapes in one multi-tensor launch."""
+
+    @staticmethod
+    def forward(ctx, scales, *tensors):
+        ctx.scales = scales
+        return tuple(torch._foreach_mul(list(tensors), scales))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [(i, g) for i, g in enumerate(grads) if g is not None]
+        out = [None] * len(grads)
+        if live:
+            for (i, _), g in zip(live, torch._foreach_mul([g.contiguous() for _, g in live], [ctx.scales[i] for i, _ in live])):
+                out[i] = g
+        return (None,) + tuple(out)
+
+
+def _scale_all(scales, tensors):
+    return list(_ScaleAll.apply([float(s) for s in scales], *tensors))
