@@ -1068,8 +1068,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
 //   * no B masks: the top image has an all-zero 22nd row and 22nd displacement column (the DMA
 //     range check writes them) and an invalid (row, dx') simply points there;
 //   * the scalar state of a row is computed one row ahead, inside the last K-step;
-//   * finished tiles leave through ob while the next rows compute (owners dump after the row's
-//     barrier, everybody stores inside the K-steps of the row after next);
+//   * finished tiles leave through ob while the next row computes (owners dump in front of the
+//     row's barrier, everybody stores inside the last K-steps of the next row);
 //   * persistent workgroups: one per CU walks its share of the (pair, row class, channel group,
 //     strip) items; the first row of the next item is fetched during the last row of this one;
 //   * LDS images without the 4-way (top) and 2-way (A) bank conflicts of the first kernel:
@@ -1330,7 +1330,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
     };
 
     RowState rs = row_state(0);
-    int dump_tile = -1;          // tile written to ob after the previous row's barrier   (workgroup-uniform)
     int store_tile = -1;         // tile whose image in ob is stored during this row      (workgroup-uniform)
     // (row 0 of this item has landed: fetched before the loop, or during the last row of the previous
     // item and waited for at that row's barrier)
@@ -1421,6 +1420,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
           __builtin_amdgcn_sched_barrier(0);
         });
       });
+      // ---- a tile that ends on this row (not the last one: 4 t + 13 == w).  Its owners write it to ob
+      // right here, BEFORE the row barrier: their accumulators are final, ob is free (its last image
+      // was stored rows ago), and a wave that reaches this point early would otherwise only wait.
+      int ending = -1;
+#ifdef UNFLOW_TUNE_NOSTORE
+      if (C < 0)                               // diagnostic: never true at run time, opaque to the compiler
+#endif
+      if (more) {
+        const int t = (w - (TP - 1 + R)) >> 2;
+        if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
+          if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
+          ending = t;
+        }
+      }
       // Row barrier.  vmcnt counts loads, LDS-DMA and stores together, in issue order: the four tile
       // stores of this row are this wave's youngest operations, and waiting for their
       // acknowledgement (microseconds under load) is not needed for anything -- only the DMA of the
@@ -1429,43 +1442,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
       if (store_tile >= 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else UNFLOW_BARRIER_DMA();
       UNFLOW_STAMP(rowc, 3);
-
-      // ---- epilogue pipeline; workgroup-uniform control
-      store_tile = dump_tile;      // dumped after the previous barrier: stored during the next row
-      dump_tile = -1;
+      store_tile = ending;         // in ob since before the barrier: stored inside the K-steps of the next row
       rs = rn;
 #ifdef UNFLOW_TUNE_NOSTORE
-      if (C > 0) { store_tile = -1; continue; }    // diagnostic: always true at run time, opaque to the compiler
+      if (C > 0) continue;
 #endif
-      if (more) {
-        // at most one tile ends on a row that is not the last: 4 t + 13 == w
-        const int t = (w - (TP - 1 + R)) >> 2;
-        if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
-          if (w + 2 <= hs - 1) {                 // room for the two riding rows
-            if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
-            dump_tile = t;
-          } else {                               // too close to the end: synchronous
-            if (store_tile >= 0) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
-              store_tile = -1;
-              UNFLOW_BARRIER_LDS();
-            }
-            if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
-            UNFLOW_BARRIER_LDS();
-#pragma unroll
-            for (int q = 0; q < 4; ++q) store_piece(t, q);
-            UNFLOW_BARRIER_LDS();
-          }
-        }
-      } else {
-        // last row: flush the pipeline, then every tile that is still live ends here
-        if (store_tile >= 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
-          store_tile = -1;
-          UNFLOW_BARRIER_LDS();
-        }
+      if (!more) {
+        // last row: every tile that is still live ends here -- dump, barrier, store, barrier
         const int t_first = max(0, (w - (TP - 1 + R) + 3) >> 2);     // first t with 4 t + 13 >= w
         for (int t = t_first; t < ntiles; ++t) {
           if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
