@@ -598,7 +598,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
         }
         if constexpr (!F16) {
           constexpr int PER_GROUP = (2 * St::PER_WAVE + GROUPS - 1) / GROUPS;   // all DMA in the first K-step
+#ifdef UNFLOW_TUNE_FWD_NODMA
+          if (more && C < 0) {
+#else
           if (more) {
+#endif
             if (kk == 0) st.template issue_range<g * PER_GROUP, PER_GROUP>(nxt);
             else st.template issue_range<(TQH + g) * PER_GROUP, PER_GROUP>(nxt);
           }
@@ -680,6 +684,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
         const int y = S * (ys0 + r) + cy;
         const int x = S * xs0 + c4 * 4;
         if (y >= H || x >= W) continue;
+#ifdef UNFLOW_TUNE_FWD_NOSTORE
+        if (C > 0 && idx > 0) continue;
+#endif
         const float *src = ob + (r * RW + c4 * 4) * (SLAB_DYH * GW) + ddl * GW + dxx;
         const float4 v = make_float4(src[0], src[SLAB_DYH * GW], src[2 * SLAB_DYH * GW], src[3 * SLAB_DYH * GW]);
         auto *dst = out + (item * D + d) * plane + (long long)y * W + x;
@@ -1368,9 +1375,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
         if constexpr (q + 1 < KSTEPS) static_for<4 * h, 4 * h + 4>([&](auto M) { read_a(Int<q + 1>{}, M); });
         if constexpr (h == 0) {
           if constexpr (q + 1 < KSTEPS) static_for<0, RING>([&](auto SL) { read_b(Int<q + 1>{}, SL); });
+#if defined(UNFLOW_TUNE_DMA_EARLY)      // both kinds in K-steps 0, 1: two pieces per chunk
+          if constexpr (q < 2) { if (fetch && !UNFLOW_TUNE_NODMA2) { issue_a(fc, 2 * q, wn, nxt); issue_a(fc, 2 * q + 1, wn, nxt); } }
+        } else {
+          if constexpr (q < 2) { if (fetch && !UNFLOW_TUNE_NODMA2) { issue_t(fc, 2 * q, wn, nxt); issue_t(fc, 2 * q + 1, wn, nxt); } }
+#elif defined(UNFLOW_TUNE_DMA_TFIRST)   // the top pieces (HBM misses) first, the A pieces (L2 hits) behind
+          if constexpr (q < T_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_t(fc, q, wn, nxt); }
+        } else {
+          if constexpr (q < A_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_a(fc, q, wn, nxt); }
+#else
           if constexpr (q < A_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_a(fc, q, wn, nxt); }
         } else {
           if constexpr (q < T_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_t(fc, q, wn, nxt); }
+#endif
           // the pending tile store goes LAST among the row's vector-memory operations (K-steps 4, 5:
           // behind the last DMA piece), so that the barrier can wait for the DMA without the stores
           if constexpr (q >= KSTEPS - 2) {
