@@ -476,7 +476,7 @@ def main():
         dt_bidir = max_over_ranks(time.perf_counter() - t1)
 
     # in-run check of the fused loss kernels the step times (every rank checks its own shard)
-    fused = float(wl.loss_leg()["ternary"])
+    fused = float(wl.loss_leg()["ternary"].detach())
     composed = float(wl.composed_loss())
     if not abs(fused - composed) <= 1e-6 * abs(composed):
         raise AssertionError("bench: fused loss %.9g != composed HIP loss %.9g" % (fused, composed))

@@ -103,3 +103,27 @@ def test_downsample_dispatcher_mirrors_reference():
         util.resize_area(torch.zeros(1, 5, 4, 1), (0, 2))
     with pytest.raises(RuntimeError, match="no CPU kernels"):
         util.downsample(torch.zeros(1, 4, 4, 1), 2)     # even extent reaches the op
+
+
+def test_matrix_kernels_keep_their_accumulators_in_registers(tmp_path):
+    """A lambda that captures the accumulator array of the correlation kernels and picks a ring slot at
+    run time makes the compiler keep the whole array in scratch memory (352 B per lane, 10x slower --
+    it happened twice in round 2 and only cycle stamps showed it).  Compile the file for gfx950 with
+    the resource-usage remarks on and hold every kernel to a few spilled scalars at most."""
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "unflow_amd", "csrc", "correlation_mfma.hip")
+    out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-Wno-pass-failed",
+                          "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", str(tmp_path / "x.o"), src],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) >= 8, out.stderr[-1000:]
+    worst = {n: s for n, s in zip(names, scratch) if s > 0}
+    assert all(s <= 128 for s in worst.values()), worst
+    hot = [s for n, s in zip(names, scratch) if "fwd_half_kernelILi4ELb0" in n or "bwd2" in n]
+    assert len(hot) == 3 and max(hot) <= 64, list(zip(names, scratch))

@@ -368,6 +368,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   }
 }
 
+#ifdef UNFLOW_TUNE_STAMPS
+// Diagnostic build only (tools/variants.sh): shader-clock stamps of a few workgroups, read back
+// through unflow_debug_read_stamps().  [block 0..STAMP_BLOCKS)[wave 0 / wave 4][row][stamp]
+constexpr int STAMP_BLOCKS = 8, STAMP_ROWS = 128, STAMP_PER_ROW = 4;
+__device__ unsigned long long g_stamps[STAMP_BLOCKS * 2 * (STAMP_ROWS + 1) * STAMP_PER_ROW];
+#define UNFLOW_STAMP(ROW, WHICH)                                                                            \
+  do {                                                                                                      \
+    if (stamp_slot >= 0 && (threadIdx.x & 63) == 0 && (ROW) <= STAMP_ROWS)                                  \
+      g_stamps[(stamp_slot * (STAMP_ROWS + 1) + (ROW)) * STAMP_PER_ROW + (WHICH)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define UNFLOW_STAMP(ROW, WHICH) do {} while (0)
+#endif
+
 // ===========================================================================
 // Forward, two workgroups per CU.  The kernel above holds 36 accumulator tiles
 // per wave (256 VGPRs, one 8-wave workgroup per CU): whenever that workgroup waits
@@ -573,7 +587,16 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
   __syncthreads();
 
   constexpr int GROUPS = (KC / 4) * TQH;                             // 6 MFMA groups per chunk
+#ifdef UNFLOW_TUNE_STAMPS
+  int stamp_slot = -1;           // workgroups 0..3 and 1000..1003, waves 0 and 4
+  {
+    const int bsel = (int)blockIdx.x < 4 ? (int)blockIdx.x : ((int)blockIdx.x >= 1000 && (int)blockIdx.x < 1004 ? (int)blockIdx.x - 996 : -1);
+    if (!F16 && bsel >= 0 && (wave == 0 || wave == 4)) stamp_slot = bsel * 2 + (wave >> 2);
+  }
+  UNFLOW_STAMP(STAMP_ROWS, 0);
+#endif
   for (int ch = 0; ch < nchunks; ++ch) {
+    UNFLOW_STAMP(ch, 0);
     const float *cur = lds + (ch & 1) * STAGEH;
     float *nxt = lds + ((ch + 1) & 1) * STAGEH;
     const bool more = ch + 1 < nchunks;
@@ -614,8 +637,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
     if constexpr (F16) {
       if (more) st.store(nxt);
     }
+    UNFLOW_STAMP(ch, 2);
     __syncthreads();
+    UNFLOW_STAMP(ch, 3);
   }
+  UNFLOW_STAMP(STAMP_ROWS, 1);   // epilogue starts
 
   // ---- epilogue (see the full-window kernel): two slabs of 6 displacement rows,
   // dy' = 9*half + 6*s + ddl; local tile row tl holds dy' = 4*(3*half + tl) + u.
@@ -706,6 +732,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
   };
   if (half == 0) epilogue(Int<0>{});
   else epilogue(Int<1>{});
+  UNFLOW_STAMP(STAMP_ROWS, 2);   // epilogue done
 }
 
 // ===========================================================================
@@ -748,19 +775,6 @@ constexpr int SW_LDS = 2 * SW_STAGE + SW_OUT;   // 37888 floats = 148 KB
 constexpr int KSTEPS = WIN / 4;                 // 6 K-steps per window row and tile
 constexpr int RING = 3;                         // live tiles per wave
 
-#ifdef UNFLOW_TUNE_STAMPS
-// Diagnostic build only (tools/variants.sh): shader-clock stamps of a few workgroups, read back
-// through unflow_debug_read_stamps().  [block 0..STAMP_BLOCKS)[wave 0 / wave 4][row][stamp]
-constexpr int STAMP_BLOCKS = 8, STAMP_ROWS = 128, STAMP_PER_ROW = 4;
-__device__ unsigned long long g_stamps[STAMP_BLOCKS * 2 * (STAMP_ROWS + 1) * STAMP_PER_ROW];
-#define UNFLOW_STAMP(ROW, WHICH)                                                                            \
-  do {                                                                                                      \
-    if (stamp_slot >= 0 && (threadIdx.x & 63) == 0 && (ROW) <= STAMP_ROWS)                                  \
-      g_stamps[(stamp_slot * (STAMP_ROWS + 1) + (ROW)) * STAMP_PER_ROW + (WHICH)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define UNFLOW_STAMP(ROW, WHICH) do {} while (0)
-#endif
 
 // First-generation row sweep: kept for fp16 storage, C % 128 != 0 and rows that are not 16-byte
 // aligned (the float32 FlowNetC shape runs corr_mfma_bwd2_kernel below).
@@ -1350,7 +1364,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
         cur_item = decode(it + it_stride);
         fc = make_fetch(cur_item);
       }
+#ifdef UNFLOW_TUNE_YOUNG_NOEXTRA     // diagnostic (wrong results): the younger half of the workgroup issues no DMA
+      const bool fetch = (more || !last_item) && ph == 0;
+#else
       const bool fetch = more || !last_item;
+#endif
       const int wn = more ? w + 1 : 0;
       RowState rn;                               // state of row w + 1, produced in the last K-step
 
