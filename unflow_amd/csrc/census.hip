@@ -720,6 +720,63 @@ __global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__
   }
 }
 
+// Tile form of the kernel above (see warp.hip, "Fast paths"): a 256-thread block owns a 64 x 8 pixel
+// tile, a lane two pixels of one column; both flows are loaded together, then all eight taps, and the
+// tile decomposition is done once per block in 32-bit arithmetic.  Same arithmetic per pixel.
+constexpr int kOccPPL = 2, kOccTileH = kTileH * kOccPPL;
+__global__ __launch_bounds__(256) void fb_occlusion_warp_tile_kernel(const float2 *__restrict__ flow,
+                                                                     const float2 *__restrict__ flow_other,
+                                                                     float2 *__restrict__ warped_out,
+                                                                     float *__restrict__ occ, const float *mask_in,
+                                                                     float *mask_out, int H, int W, int ntx, int nty,
+                                                                     int unwarped_magnitude) {
+  const int tile = blockIdx.x;
+  const int tx = tile % ntx, ty = (tile / ntx) % nty, b = tile / (ntx * nty);
+  const int x = tx * kTileW + (threadIdx.x & (kTileW - 1));
+  const int y0 = ty * kOccTileH + (threadIdx.x >> 6);
+  const long long item = (long long)b * H * W;
+  const float2 *fl = flow + item, *base = flow_other + item;
+  bool ok[kOccPPL];
+  unsigned pix[kOccPPL];
+  float2 f[kOccPPL];
+#pragma unroll
+  for (int i = 0; i < kOccPPL; ++i) {
+    const int y = y0 + kTileH * i;
+    ok[i] = x < W && y < H;
+    pix[i] = (unsigned)(min(y, H - 1) * W + min(x, W - 1));
+    f[i] = fl[pix[i]];
+  }
+  float2 ta[kOccPPL], tb[kOccPPL], tc[kOccPPL], td[kOccPPL], fo[kOccPPL];
+  float xw[kOccPPL], yw[kOccPPL];
+#pragma unroll
+  for (int i = 0; i < kOccPPL; ++i) {
+    const ClampTaps t = clamp_taps(min(x, W - 1), min(y0 + kTileH * i, H - 1), f[i], H, W);
+    xw[i] = t.xw;
+    yw[i] = t.yw;
+    ta[i] = base[(unsigned)t.ia];
+    tb[i] = base[(unsigned)t.ib];
+    tc[i] = base[(unsigned)t.ic];
+    td[i] = base[(unsigned)t.id];
+    if (unwarped_magnitude) fo[i] = base[pix[i]];
+  }
+#pragma unroll
+  for (int i = 0; i < kOccPPL; ++i) {
+    const float wa = (1.f - xw[i]) * (1.f - yw[i]), wb = (1.f - xw[i]) * yw[i];
+    const float wc = xw[i] * (1.f - yw[i]), wd = xw[i] * yw[i];
+    float2 w;
+    w.x = add_rn(add_rn(add_rn(mul_rn(wa, ta[i].x), mul_rn(wb, tb[i].x)), mul_rn(wc, tc[i].x)), mul_rn(wd, td[i].x));
+    w.y = add_rn(add_rn(add_rn(mul_rn(wa, ta[i].y), mul_rn(wb, tb[i].y)), mul_rn(wc, tc[i].y)), mul_rn(wd, td[i].y));
+    float du, dv;
+    const float o = fb_occluded(f[i], w, unwarped_magnitude ? fo[i] : w, du, dv);
+    if (ok[i]) {
+      const long long p = item + pix[i];
+      if (warped_out) warped_out[p] = w;
+      if (occ) occ[p] = o;
+      if (mask_out) mask_out[p] = mask_in[p] * (1.f - o);     // mask_in may be mask_out (in place)
+    }
+  }
+}
+
 // losses['sym'] of one direction (losses.py:60-61): charbonnier_loss(occ - disocc) with
 // occ = 1 - mask (:57-58) and disocc = cast(density < thresh) (:27-29), one pass
 // instead of compare, cast, two subtractions and the reduction.
@@ -953,6 +1010,15 @@ extern "C" int unflow_fb_occlusion_warp(const float *flow, const float *flow_oth
   if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp: negative dimension");
   if (n == 0) return UNFLOW_OK;
   if (mask_out && !mask_in) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp: mask_out needs mask_in");
+  const int ntx = (W + kTileW - 1) / kTileW, nty = (H + kOccTileH - 1) / kOccTileH;
+  const long long tiles = (long long)B * ntx * nty;
+  if ((long long)H * W < (1LL << 30) && tiles < (1LL << 31)) {      // 32-bit offsets inside an item, one block per tile
+    hipLaunchKernelGGL(fb_occlusion_warp_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other),
+                       reinterpret_cast<float2 *>(flow_other_warped), occ, mask_in, mask_out, H, W, ntx, nty,
+                       unwarped_magnitude);
+    return launch_status("fb_occlusion_warp");
+  }
   const long long vn = tiled_total(B, H, W);
   hipLaunchKernelGGL(fb_occlusion_warp_kernel, dim3(ew_grid(vn)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other),
