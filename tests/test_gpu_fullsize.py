@@ -269,3 +269,32 @@ def test_batch_shards_sum_to_whole_batch_cfg3(dev):
             assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
     for k in terms:
         np.testing.assert_allclose(total[k], whole[k], rtol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("C", [3, 2])
+def test_image_warp_image_gradient_fixed_point_full_size(oracle_mod, dev, C):
+    """The scatter-add of image_warp's image gradient accumulates in two-word fixed point with a
+    per-tile scale.  One full-size item with the bench's smooth flow and an upstream
+    gradient whose magnitude spans nine decades (and a few exact zeros), against the oracle's float
+    adds: 1e-5 of the gradient's scale overall, and -- the point of the second word -- 1e-5 of the LOCAL
+    scale inside every 64 x 64 block, so small gradients next to large ones keep their digits."""
+    import bench
+    from unflow_amd.image_warp import image_warp_grad
+    wl = bench.Workload(1, dev, seed=4321, global_batch=1, features=False)
+    rng = np.random.default_rng(C)
+    mag = 10.0 ** rng.uniform(-6, 3, size=(1, H // 64, W // 64, 1)).astype(np.float32)       # one decade per 64x64 block
+    g = (rng.standard_normal((1, H, W, C)).astype(np.float32) * np.repeat(np.repeat(mag, 64, 1), 64, 2))
+    g[0, 100:110, 200:260] = 0.0
+    im = wl.im2[..., :C].contiguous()
+    flow = wl.flow_fw.detach()
+    got, _ = image_warp_grad(torch.from_numpy(g).to(dev), im, flow, True, False)
+    want, _ = oracle_mod.image_warp_grad(g, im.cpu().numpy(), flow.cpu().numpy(), want_flow=False)
+    got = got.cpu().numpy()
+    assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
+    err = np.abs(got - want).reshape(H // 64, 64, W // 64, 64, C).max(axis=(1, 3, 4))
+    ref = np.abs(want).reshape(H // 64, 64, W // 64, 64, C).max(axis=(1, 3, 4))
+    # a block's taps reach a few pixels into its neighbours (flow up to ~30 px): compare with the
+    # largest scale among the block and its 8 neighbours
+    pad = np.pad(ref, 1, mode="edge")
+    local = np.max([pad[1 + dy:1 + dy + ref.shape[0], 1 + dx:1 + dx + ref.shape[1]] for dy in (-1, 0, 1) for dx in (-1, 0, 1)], axis=0)
+    assert (err <= 1e-5 * local).all(), float((err / local).max())

@@ -13,6 +13,8 @@
 #include "common.h"
 #include "warp_taps.h"
 
+#include <cstdint>
+
 namespace unflow {
 namespace {
 
@@ -867,6 +869,42 @@ __global__ __launch_bounds__(kBlock) void downsample_kernel(const float *__restr
   }
 }
 
+// Downsample for the shapes the loss pyramid uses (C <= 3, scale 2 or 4): one lane per OUTPUT PIXEL.
+// The scale*C floats a pixel takes from one input row are contiguous and 8- (scale 2) or 16-byte
+// (scale 4) aligned, so a row is C vector loads instead of scale*C strided scalar ones, and a wave
+// reads whole rows.  Per channel the taps are added in the same row-major order as above.
+template <int C, int SCALE>
+__global__ __launch_bounds__(kBlock) void downsample_px_kernel(const float *__restrict__ images,
+                                                               float *__restrict__ output, int in_width,
+                                                               int out_height, int out_width, long long npx) {
+  typedef float vec_t __attribute__((ext_vector_type(SCALE)));       // SCALE floats: C of them per row
+  const long long p = blockIdx.x * (long long)kBlock + threadIdx.x;
+  if (p >= npx) return;
+  const int x = (int)(p % out_width);
+  const long long by = p / out_width;                                  // b * out_height + y
+  const vec_t *src = reinterpret_cast<const vec_t *>(images + (by * SCALE * in_width + (long long)x * SCALE) * C);
+  float sum[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) sum[c] = 0.f;
+  vec_t row[SCALE][C];
+#pragma unroll
+  for (int dy = 0; dy < SCALE; ++dy)
+#pragma unroll
+    for (int k = 0; k < C; ++k) row[dy][k] = __builtin_nontemporal_load(src + (long long)dy * (in_width * C / SCALE) + k);   // W % SCALE == 0
+#pragma unroll
+  for (int dy = 0; dy < SCALE; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < SCALE; ++dx)
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const int e = dx * C + c;                                      // float index inside the row's SCALE*C span
+        sum[c] += row[dy][e / SCALE][e % SCALE];
+      }
+  float *out = output + p * C;
+#pragma unroll
+  for (int c = 0; c < C; ++c) out[c] = sum[c] / (float)(SCALE * SCALE);
+}
+
 // Image gradient of image_warp (the scatter-add TF derives from tf.gather), LDS-privatised.
 // One workgroup owns a 64x16 tile of pixels; the cells its 2x2 taps touch form a bounding
 // box that -- for a coherent flow -- is little larger than the tile.  The taps are added
@@ -1173,6 +1211,17 @@ extern "C" int unflow_downsample_fwd(const float *images, float *output, int B, 
   const int oh = H / scale, ow = W / scale;
   const long long total = (long long)B * oh * ow * C;
   if (total == 0) return UNFLOW_OK;
+  const long long npx = (long long)B * oh * ow;
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(images) & 15) == 0 && npx < (1LL << 31) * kBlock;
+  if (vec_ok && C >= 1 && C <= 3 && (scale == 2 || scale == 4)) {
+    const dim3 g((unsigned)((npx + kBlock - 1) / kBlock));
+    hipStream_t s = as_stream(stream);
+#define DS_LAUNCH(C_, S_) hipLaunchKernelGGL((downsample_px_kernel<C_, S_>), g, dim3(kBlock), 0, s, images, output, W, oh, ow, npx)
+    if (scale == 2) { if (C == 1) DS_LAUNCH(1, 2); else if (C == 2) DS_LAUNCH(2, 2); else DS_LAUNCH(3, 2); }
+    else { if (C == 1) DS_LAUNCH(1, 4); else if (C == 2) DS_LAUNCH(2, 4); else DS_LAUNCH(3, 4); }
+#undef DS_LAUNCH
+    return launch_status("downsample");
+  }
   hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), images,
                      output, H, W, C, oh, ow, scale, total);
   return launch_status("downsample");
