@@ -1352,69 +1352,72 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
 
     RowState rs = row_state(0);
     int store_tile = -1;         // tile whose image in ob is stored during this row      (workgroup-uniform)
-    // (row 0 of this item has landed: fetched before the loop, or during the last row of the previous
-    // item and waited for at that row's barrier)
+    int dumped = -1;             // tile written to ob behind the previous row's last K-step: visible after this row's barrier
+    // (row 0 of this item has landed: fetched before the loop, or during the last rows of the previous
+    // item and waited for at the last row's barrier)
 
+    // The row barrier stands between K-steps 4 and 5, not between rows: when it opens, the 12 MFMAs of
+    // K-step 5 are ready to issue (operands in registers) and the first fragments of row w + 1 -- whose
+    // image the barrier has just declared complete -- are read behind them, so neither the barrier
+    // round trip nor the LDS latency of the first fragments meets an empty matrix pipe.  Nothing reads
+    // row w's image after K-step 4's chunks, so that buffer takes the DMA of row w + 2 from K-step 5 on:
+    // piece 0 rides K-step 5 of row w, pieces 1..3 K-steps 0..2 of row w + 1, two K-steps ahead of the
+    // barrier that needs them, as before.
+    static_assert(A_PER_WAVE == 4 && T_PER_WAVE == 4, "DMA schedule: piece 0 in K-step 5, pieces 1..3 in K-steps 0..2");
+    float abuf[MTS], bbuf[2][RING];
     for (int w = 0; w < hs; ++w, ++rowc) {
       UNFLOW_STAMP(rowc, 0);
       const float *cur = lds + (rowc & 1) * STAGE2;
       float *nxt = lds + ((rowc + 1) & 1) * STAGE2;
       const bool more = w + 1 < hs;
-      if (!more && !last_item) {                 // the fetch of the next item's first row rides this row
-        cur_item = decode(it + it_stride);
-        fc = make_fetch(cur_item);
-      }
-#ifdef UNFLOW_TUNE_YOUNG_NOEXTRA     // diagnostic (wrong results): the younger half of the workgroup issues no DMA
-      const bool fetch = (more || !last_item) && ph == 0;
-#else
-      const bool fetch = more || !last_item;
-#endif
+      // pieces 1..3 of the next sweep row (the next item's row 0 behind the last row: fc was replaced
+      // in front of the previous row's barrier)
+      const bool fetch = (more || !last_item) && !UNFLOW_TUNE_NODMA2;
       const int wn = more ? w + 1 : 0;
-      RowState rn;                               // state of row w + 1, produced in the last K-step
+      // piece 0 of the sweep row after that, into this row's buffer
+      const bool fetch5 = (w + 2 < hs || (w + 2 == hs && !last_item)) && !UNFLOW_TUNE_NODMA2;
+      const int w5 = w + 2 < hs ? w + 2 : 0;
+      RowState rn;                               // state of row w + 1, produced in K-step 4
 
-      // ---- one row: 6 K-steps x 2 halves of the M-tiles x 3 ring slots, 4 MFMAs each; behind every
-      // half a short chunk of the other work (fragment reads of the next K-step, one DMA piece of
-      // the next row, a slice of a pending tile store, the next row's state), pinned there by
-      // scheduling barriers so that it never collects into a long stretch without MFMAs.
-      float abuf[MTS], bbuf[2][RING];
-      auto read_a = [&](auto Q, auto M) __attribute__((always_inline)) {
+      auto read_a = [&](const float *img, auto Q, auto M) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value, m = decltype(M)::value;
-        abuf[m] = cur[a_off + m * 16 * ACS + 4 * S * q];
+        abuf[m] = img[a_off + m * 16 * ACS + 4 * S * q];
       };
-      auto read_b = [&](auto Q, auto SL) __attribute__((always_inline)) {
+      auto read_b = [&](const float *img, const RowState &st, auto Q, auto SL) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value, sl = decltype(SL)::value;
-        bbuf[q & 1][sl] = cur[rs.b_row[sl] + b_dx[q]];
+        bbuf[q & 1][sl] = img[st.b_row[sl] + b_dx[q]];
       };
       // The other work of K-step q comes in two chunks, one behind each half of the M-tiles.  The A
       // fragments are single-buffered: M-tiles 0..3 are free once half 0 is through and are re-read
-      // (for K-step q+1) right then, M-tiles 4..7 behind half 1 -- up to 12 MFMAs ahead of their use.
+      // (for the next K-step) right then, M-tiles 4..7 behind half 1 -- up to 12 MFMAs ahead of their use.
       auto chunk = [&](auto Q, auto H) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value, h = decltype(H)::value;
-        if constexpr (q + 1 < KSTEPS) static_for<4 * h, 4 * h + 4>([&](auto M) { read_a(Int<q + 1>{}, M); });
-        if constexpr (h == 0) {
-          if constexpr (q + 1 < KSTEPS) static_for<0, RING>([&](auto SL) { read_b(Int<q + 1>{}, SL); });
-#if defined(UNFLOW_TUNE_DMA_EARLY)      // both kinds in K-steps 0, 1: two pieces per chunk
-          if constexpr (q < 2) { if (fetch && !UNFLOW_TUNE_NODMA2) { issue_a(fc, 2 * q, wn, nxt); issue_a(fc, 2 * q + 1, wn, nxt); } }
-        } else {
-          if constexpr (q < 2) { if (fetch && !UNFLOW_TUNE_NODMA2) { issue_t(fc, 2 * q, wn, nxt); issue_t(fc, 2 * q + 1, wn, nxt); } }
-#elif defined(UNFLOW_TUNE_DMA_TFIRST)   // the top pieces (HBM misses) first, the A pieces (L2 hits) behind
-          if constexpr (q < T_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_t(fc, q, wn, nxt); }
-        } else {
-          if constexpr (q < A_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_a(fc, q, wn, nxt); }
-#else
-          if constexpr (q < A_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_a(fc, q, wn, nxt); }
-        } else {
-          if constexpr (q < T_PER_WAVE) { if (fetch && !UNFLOW_TUNE_NODMA2) issue_t(fc, q, wn, nxt); }
-#endif
-          // the pending tile store goes LAST among the row's vector-memory operations (K-steps 4, 5:
-          // behind the last DMA piece), so that the barrier can wait for the DMA without the stores
-          if constexpr (q >= KSTEPS - 2) {
-            if (store_tile >= 0) {
-              store_piece(store_tile, 2 * (q - (KSTEPS - 2)));
-              store_piece(store_tile, 2 * (q - (KSTEPS - 2)) + 1);
-            }
+        if constexpr (q + 1 < KSTEPS) {
+          static_for<4 * h, 4 * h + 4>([&](auto M) { read_a(cur, Int<q + 1>{}, M); });
+          if constexpr (h == 0) static_for<0, RING>([&](auto SL) { read_b(cur, rs, Int<q + 1>{}, SL); });
+        } else if (more) {                       // K-step 5: the first fragments of row w + 1
+          static_for<4 * h, 4 * h + 4>([&](auto M) { read_a(nxt, Int<0>{}, M); });
+          if constexpr (h == 0) static_for<0, RING>([&](auto SL) { read_b(nxt, rn, Int<0>{}, SL); });
+        }
+        if constexpr (q < 3) {                   // pieces 1..3 of the next sweep row
+          if (fetch) {
+            if constexpr (h == 0) issue_a(fc, q + 1, wn, nxt);
+            else issue_t(fc, q + 1, wn, nxt);
           }
-          if constexpr (q == KSTEPS - 1) rn = row_state(w + 1);
+        } else if constexpr (q == KSTEPS - 1) {  // piece 0 of the one after
+          if (fetch5) {
+            if constexpr (h == 0) issue_a(fc, 0, w5, const_cast<float *>(cur));
+            else issue_t(fc, 0, w5, const_cast<float *>(cur));
+          }
+        } else if constexpr (h == 1) {
+          // K-steps 3, 4: the pending tile store goes LAST among the vector-memory operations in front
+          // of the barrier (behind the last DMA piece), so that the barrier can wait for the DMA
+          // without the stores
+          if (store_tile >= 0) {
+            store_piece(store_tile, 2 * (q - 3));
+            store_piece(store_tile, 2 * (q - 3) + 1);
+          }
+          if constexpr (q == 4) rn = row_state(w + 1);
         }
       };
       // wave-uniform (forced into scalar registers: the compiler would otherwise rebuild them from a
@@ -1422,52 +1425,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
       const bool live0 = __builtin_amdgcn_readfirstlane(rs.tile[0]) >= 0;
       const bool live1 = __builtin_amdgcn_readfirstlane(rs.tile[1]) >= 0;
       const bool live2 = __builtin_amdgcn_readfirstlane(rs.tile[2]) >= 0;
-      // first fragments (their latency is exposed once per row)
-      static_for<0, MTS>([&](auto M) { read_a(Int<0>{}, M); });
-      static_for<0, RING>([&](auto SL) { read_b(Int<0>{}, SL); });
+      if (w == 0) {
+        // first row of an item: nothing ran ahead of it -- its first fragments (latency exposed once
+        // per item) and piece 0 of row 1
+        static_for<0, MTS>([&](auto M) { read_a(cur, Int<0>{}, M); });
+        static_for<0, RING>([&](auto SL) { read_b(cur, rs, Int<0>{}, SL); });
+        if (more && !UNFLOW_TUNE_NODMA2) {
+          issue_a(fc, 0, 1, nxt);
+          issue_t(fc, 0, 1, nxt);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       UNFLOW_STAMP(rowc, 1);
-      static_for<0, KSTEPS>([&](auto Q) {
+      auto kstep = [&](auto Q) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value;
-#ifdef UNFLOW_TUNE_PRIO   // measured: +1 % without the DMA, -3 % with it; not used
-        // The older half of the workgroup (waves 0..3) wins every arbitration for the SIMD it shares
-        // with a wave of the younger half, finishes its row ~1700 cycles early and leaves the partner
-        // to work off its MFMAs alone, which a single wave cannot do at the full rate.  Raising the
-        // younger half's priority in every other K-step lets both halves reach the barrier together.
-        if (ph == 1) {
-          if constexpr (q & 1) __builtin_amdgcn_s_setprio(1);
-          else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
         static_for<0, 2>([&](auto H) {
           constexpr int m0 = decltype(H)::value * (MTS / 2);
           static_for<0, RING>([&](auto SL) {
             constexpr int sl = decltype(SL)::value;
             // a dead ring slot skips its MFMAs: one wave-uniform branch per 4
             if (sl == 0 ? live0 : (sl == 1 ? live1 : live2)) {
+#ifdef UNFLOW_TUNE_NOMFMA      // diagnostic (wrong results): everything but the matrix instructions
+              {
+                const float a0_ = abuf[m0], a1_ = abuf[m0 + 1], a2_ = abuf[m0 + 2], a3_ = abuf[m0 + 3], b_ = bbuf[q & 1][sl];
+                asm volatile("" :: "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_), "v"(b_));
+              }
+#else
 #pragma unroll
               for (int m = m0; m < m0 + MTS / 2; ++m)
                 acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[m], bbuf[q & 1][sl], acc[sl][m], 0, 0, 0);
+#endif
             }
           });
           __builtin_amdgcn_sched_barrier(0);
           chunk(Q, H);
           __builtin_amdgcn_sched_barrier(0);
         });
-      });
-      // ---- a tile that ends on this row (not the last one: 4 t + 13 == w).  Its owners write it to ob
-      // right here, BEFORE the row barrier: their accumulators are final, ob is free (its last image
-      // was stored rows ago), and a wave that reaches this point early would otherwise only wait.
-      int ending = -1;
-#ifdef UNFLOW_TUNE_NOSTORE
-      if (C < 0)                               // diagnostic: never true at run time, opaque to the compiler
-#endif
-      if (more) {
-        const int t = (w - (TP - 1 + R)) >> 2;
-        if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
-          if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
-          ending = t;
-        }
+      };
+      static_for<0, KSTEPS - 1>([&](auto Q) { kstep(Q); });
+      // the description of the next item replaces this one once the last DMA of this item is out
+      // (pieces 1..3 of row hs - 1, in K-steps 0..2 of row hs - 2): here, in front of the barrier, where
+      // a wave that is early would only wait
+      if (w + 2 == hs && !last_item) {
+        cur_item = decode(it + it_stride);
+        fc = make_fetch(cur_item);
       }
       // Row barrier.  vmcnt counts loads, LDS-DMA and stores together, in issue order: the four tile
       // stores of this row are this wave's youngest operations, and waiting for their
@@ -1477,13 +1478,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
       if (store_tile >= 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else UNFLOW_BARRIER_DMA();
       UNFLOW_STAMP(rowc, 3);
-      store_tile = ending;         // in ob since before the barrier: stored inside the K-steps of the next row
+      kstep(Int<KSTEPS - 1>{});
+      // ---- a tile that ends on this row (not the last one: 4 t + 13 == w): its owners write it to ob
+      // (free: its last image was stored two rows ago); the next barrier publishes it and the row after
+      // that stores it inside its K-steps 3, 4.
+      store_tile = dumped;
+      dumped = -1;
+#ifdef UNFLOW_TUNE_NOSTORE
+      if (C < 0)                               // diagnostic: never true at run time, opaque to the compiler
+#endif
+      if (more) {
+        const int t = (w - (TP - 1 + R)) >> 2;
+        if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
+          if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
+          dumped = t;
+        }
+      }
       rs = rn;
 #ifdef UNFLOW_TUNE_NOSTORE
       if (C > 0) continue;
 #endif
       if (!more) {
-        // last row: every tile that is still live ends here -- dump, barrier, store, barrier
+        // last row: the tile published by this row's barrier is still to be stored, and every tile that
+        // is still live ends here -- (store,) barrier, dump, barrier, store, ...
+        if (store_tile >= 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
+          UNFLOW_BARRIER_LDS();                  // ob is rewritten below
+        }
         const int t_first = max(0, (w - (TP - 1 + R) + 3) >> 2);     // first t with 4 t + 13 >= w
         for (int t = t_first; t < ntiles; ++t) {
           if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
@@ -1610,7 +1632,7 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
 #ifdef UNFLOW_TUNE_OLD_BWD
   if (false) {
 #else
-  if (wide && full) {
+  if (wide && full && H >= 4) {   // (its DMA runs two class rows ahead: a row class has >= 2 rows)
 #endif
     // second-generation kernel: persistent workgroups, one per CU, walking the items
     const int nitems = (int)grid.x;
