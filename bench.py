@@ -501,7 +501,7 @@ def main():
                        "parallelism": "batch-sharded x%d (one process per GPU), all-reduce of loss + 156.7 MB grad buffer" % world,
                        "world_size": world, "backend": dist.get_backend() if world > 1 else None},
             "roofline": {"bound": "mfma",
-                         "kernel": "correlation backward: corr_mfma_bwd_kernel, both gradient launches of one call",
+                         "kernel": "correlation backward: corr_mfma_bwd2_kernel, both gradient launches of one call",
                          "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP32_MATRIX_PEAK_TF,
                          "frac_basis": "HIP events around the call on the launch stream, mean over the timed region "
