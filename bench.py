@@ -580,6 +580,16 @@ def breakdown(wl, fwd_ms, bwd_ms):
     rows.append(("backward_warp C3", timeit(lambda: ops.backward_warp(wl.im2, ffw)), npx * 32))
     rows.append(("backward_warp_grad C3", timeit(lambda: ops.backward_warp_grad(g3, wl.im2, ffw)), npx * 40))
     rows.append(("forward_warp", timeit(lambda: ops.forward_warp(ffw)), npx * 12))
+    # fp16 storage of the warps (extension, BASELINE config 5): half the bytes per pixel
+    im2h, ffwh, g3h = wl.im2.half(), ffw.half(), g3.half()
+    rows.append(("image_warp C3, fp16 storage (extension)", timeit(lambda: ops.image_warp_fp16(im2h, ffwh)), npx * 16))
+    f16 = ffwh.clone().requires_grad_(True)
+    o16 = ops.image_warp_fp16(im2h, f16)
+    rows.append(("image_warp_grad flow C3, fp16 storage (extension)",
+                 timeit(lambda: torch.autograd.grad(o16, f16, g3h, retain_graph=True)), npx * 20))
+    rows.append(("backward_warp C3, fp16 storage (extension)", timeit(lambda: ops.backward_warp_fp16(im2h, ffwh)), npx * 16))
+    rows.append(("forward_warp, fp16 flows (extension)", timeit(lambda: ops.forward_warp_fp16(ffwh)), npx * 8))
+    del im2h, ffwh, g3h, f16, o16
     rows.append(("forward_warp_grad", timeit(lambda: ops.forward_warp_grad(wl.border, ffw)), npx * 16))
     # SURVEY 8d "adversarial" set: i.i.d. U(-30,30) flows (worst-case gather / splat locality)
     adv = (torch.rand((B, H, W, 2), device=ffw.device) - 0.5) * 60.0

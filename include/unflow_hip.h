@@ -36,7 +36,7 @@ extern "C" {
 #define UNFLOW_ERR_INVALID_ARGUMENT 1 /* tf errors::InvalidArgument */
 #define UNFLOW_ERR_LAUNCH 2           /* hipGetLastError() after a launch */
 
-#define UNFLOW_ABI_VERSION 2
+#define UNFLOW_ABI_VERSION 3
 
 typedef void *unflow_stream_t; /* hipStream_t */
 
@@ -249,6 +249,25 @@ int unflow_correlation_bwd_f16(const void *topdiff, const void *in0, const void 
                                void *g1, int B, int C, int H, int W, int kernel_size,
                                int max_displacement, int pad, int stride_1, int stride_2,
                                unflow_stream_t stream);
+
+/* The warps with fp16 storage (extension, BASELINE config 5: "forward_warp + full-resolution
+ * image_warp, fp16 with fp32 accumulate").  Same layouts and semantics as unflow_backward_warp_*,
+ * unflow_image_warp_* and unflow_forward_warp_fwd above with IEEE binary16 images, flows and
+ * gradients in memory: every value is widened to f32 when loaded, the arithmetic is the f32
+ * kernels' expression, the result is rounded to half once when stored.  1 <= C <= 3; all
+ * tensors 4-byte aligned; otherwise UNFLOW_ERR_INVALID_ARGUMENT.  The image gradient of
+ * image_warp has no fp16 form (its scatter-add accumulates in f32: use unflow_image_warp_bwd).
+ * forward_warp takes half flows and writes its density in f32 (the accumulator of the splat). */
+int unflow_backward_warp_fwd_f16(const void *images, const void *flows, void *output, int B, int H,
+                                 int W, int C, unflow_stream_t stream);
+int unflow_backward_warp_bwd_f16(const void *input_grad, const void *images, const void *flows,
+                                 void *output_grad, int B, int H, int W, int C, unflow_stream_t stream);
+int unflow_image_warp_fwd_f16(const void *im, const void *flow, void *warped, int B, int H, int W,
+                              int C, unflow_stream_t stream);
+int unflow_image_warp_bwd_flow_f16(const void *grad, const void *im, const void *flow, void *d_flow,
+                                   int B, int H, int W, int C, unflow_stream_t stream);
+int unflow_forward_warp_fwd_f16(const void *flows, float *output, int B, int H, int W,
+                                unflow_stream_t stream);
 
 /* ---------------------------------------------------------------- integer census (extension)
  * NOT in the reference (its census is the soft one above).  Classical ternary

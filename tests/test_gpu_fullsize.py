@@ -177,6 +177,35 @@ def test_cfg5_shapes_fp32(dev):
     im2 = torch.rand((16, 768, 1280, 3), device=dev, generator=g)
     blk = flownet.stacked_inputs(im1, im2, torch.zeros((16, 192, 320, 2), device=dev))
     assert torch.equal(blk, torch.cat([im1, im2, torch.zeros_like(flow), im2, (im2 - im1).abs()], 3))
+    del blk
+
+
+def test_cfg5_warps_fp16_storage(dev):
+    """BASELINE config 5's full-resolution warps with fp16 storage (extension): image_warp of half images
+    with half flows equals the f32 op on the widened tensors rounded to half, bit for bit, forward and flow
+    gradient; zero flow is the identity; forward_warp of half flows equals the f32 op on the widened flows."""
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp
+    g = gen(dev, 10)
+    B, H, W = 16, 768, 1280
+    im = torch.rand((B, H, W, 3), device=dev, generator=g).half()
+    flow = (torch.randn((B, H, W, 2), device=dev, generator=g) * 8).half()
+    assert torch.equal(ops.image_warp_fp16(im, torch.zeros_like(flow)), im)
+    f16 = flow.clone().requires_grad_(True)
+    out = ops.image_warp_fp16(im, f16)
+    f32 = flow.float().requires_grad_(True)
+    ref = image_warp(im.float(), f32)
+    assert torch.equal(out, ref.half())
+    gout = torch.randn(out.shape, device=dev, generator=g).half()
+    out.backward(gout)
+    ref.backward(gout.float())
+    assert torch.equal(f16.grad, f32.grad.half())
+    del out, ref, gout, f16, f32, im
+    d16 = ops.forward_warp_fp16(flow)
+    d32 = ops.forward_warp(flow.float())
+    torch.testing.assert_close(d16, d32, rtol=1e-5, atol=1e-5)
+    total = float(d32.double().sum())
+    assert abs(float(d16.double().sum()) - total) <= 1e-6 * total
 
 
 def test_bench_loss_leg_cfg3(oracle_mod, dev):

@@ -261,6 +261,61 @@ def test_correlation_fp16_storage(oracle_mod, dev, shape):
         ops.correlation_fp16(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1).to(dev))
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 37, 70, 3), (3, 5, 7, 3), (1, 16, 64, 2), (3, 9, 11, 1)])
+def test_warps_fp16_storage(oracle_mod, dev, B, H, W, C):
+    """Extension (BASELINE config 5; not in the reference): backward_warp / image_warp with half images,
+    flows and gradients in memory.  The arithmetic is the f32 kernels' on the widened values, so the result
+    equals the f32 op on the same half-rounded inputs, rounded to half (bit for bit), and the oracle's
+    within the final rounding (rtol 2e-3)."""
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp
+    rng = np.random.default_rng(B * 100 + H + C)
+    im = rng.uniform(0, 1, (B, H, W, C)).astype(np.float16)
+    flow = (rng.standard_normal((B, H, W, 2)) * 6).astype(np.float16)
+    flow[0, 0, 0] = [-0.0001, 1e-5]             # image_warp floors the FLOW: tiny negatives matter (D2b)
+    gout = rng.standard_normal((B, H, W, C)).astype(np.float16)
+    im32, fl32, g32 = im.astype(np.float32), flow.astype(np.float32), gout.astype(np.float32)
+    for name, op16, op32, fwd_o, grad_o in (
+            ("backward_warp", ops.backward_warp_fp16, ops.backward_warp, oracle_mod.backward_warp, oracle_mod.backward_warp_grad),
+            ("image_warp", ops.image_warp_fp16, image_warp, oracle_mod.image_warp,
+             lambda g, i, f: oracle_mod.image_warp_grad(g, i, f, want_im=False)[1])):
+        f = torch.from_numpy(flow).to(dev).requires_grad_(True)
+        got = op16(torch.from_numpy(im).to(dev), f)
+        assert got.dtype == torch.float16 and tuple(got.shape) == im.shape, name
+        f32 = torch.from_numpy(fl32).to(dev).requires_grad_(True)
+        ref = op32(torch.from_numpy(im32).to(dev), f32)
+        assert torch.equal(got, ref.half()), name
+        np.testing.assert_allclose(got.detach().float().cpu().numpy(), fwd_o(im32, fl32), rtol=2e-3, atol=1e-6, err_msg=name)
+        got.backward(torch.from_numpy(gout).to(dev))
+        ref.backward(torch.from_numpy(g32).to(dev))
+        assert f.grad.dtype == torch.float16
+        assert torch.equal(f.grad, f32.grad.half()), name
+        if grad_o is not None:
+            want = grad_o(g32, im32, fl32)
+            np.testing.assert_allclose(f.grad.float().cpu().numpy(), want, rtol=2e-3, atol=2e-4 * np.abs(want).max(), err_msg=name)
+    with pytest.raises(TypeError):
+        ops.image_warp_fp16(torch.from_numpy(im32).to(dev), torch.from_numpy(flow).to(dev))
+    with pytest.raises(ValueError, match="channels"):
+        ops.image_warp_fp16(torch.zeros((1, 4, 4, 5), dtype=torch.float16, device=dev), torch.zeros((1, 4, 4, 2), dtype=torch.float16, device=dev))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 40, 70), (1, 7, 130)])
+def test_forward_warp_fp16_storage(oracle_mod, dev, B, H, W):
+    """forward_warp of half flows: the density is accumulated and returned in f32 and equals the f32 op on
+    the widened flows up to the order of the float atomics of the flush."""
+    from unflow_amd import ops
+    rng = np.random.default_rng(B + H + W)
+    flow = (rng.standard_normal((B, H, W, 2)) * 5).astype(np.float16)
+    got = ops.forward_warp_fp16(torch.from_numpy(flow).to(dev))
+    assert got.dtype == torch.float32 and tuple(got.shape) == (B, H, W, 1)
+    want = oracle_mod.forward_warp(flow.astype(np.float32))
+    close(got, want, 1e-5, 1e-5)
+    ref = ops.forward_warp(torch.from_numpy(flow.astype(np.float32)).to(dev))
+    close(got, N(ref), 1e-6, 1e-6)
+    with pytest.raises(TypeError):
+        ops.forward_warp_fp16(torch.from_numpy(flow.astype(np.float32)).to(dev))
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 16, 24), (1, 7, 9, 13), (2, 16, 48, 160)])
 def test_correlation_bidirectional(oracle_mod, dev, shape):
     """Extension for the bidirectional FlowNetC (core/flownet.py:33-43): the cost volume of (b, a) is a

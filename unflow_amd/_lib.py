@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # kernel with -D knobs); never a fallback -- a missing file raises like the default path does.
 LIB_PATH = os.environ.get("UNFLOW_HIP_LIB") or os.path.join(_HERE, "libunflow_hip.so")
 
-ABI_VERSION = 2      # UNFLOW_ABI_VERSION of include/unflow_hip.h
+ABI_VERSION = 3      # UNFLOW_ABI_VERSION of include/unflow_hip.h
 UNFLOW_OK = 0
 UNFLOW_ERR_INVALID_ARGUMENT = 1
 UNFLOW_ERR_LAUNCH = 2
@@ -59,6 +59,11 @@ SIGNATURES = {
     "unflow_correlation_flip": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_fwd_f16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_bwd_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "unflow_backward_warp_fwd_f16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_backward_warp_bwd_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_image_warp_fwd_f16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_image_warp_bwd_flow_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "unflow_forward_warp_fwd_f16": (_I, [_P, _P, _I, _I, _I, _P]),
     "unflow_census_transform": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "unflow_census_hamming": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "unflow_stacked_inputs_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),

@@ -14,6 +14,7 @@
 #include "warp_taps.h"
 
 #include <cstdint>
+#include <type_traits>
 
 namespace unflow {
 namespace {
@@ -307,6 +308,63 @@ __device__ inline void nt_load_px(float (&r)[C], const float *p) {
     for (int c = 0; c < C; ++c) r[c] = v[c];
   }
 }
+// ---- fp16 STORAGE (extension, BASELINE config 5; not in the reference): the same kernels with half
+// images / flows / gradients in HBM; every value is widened to f32 when loaded, the arithmetic is
+// the f32 expression above, and the result is rounded to half once when stored.
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+template <class T> struct FlowOf { typedef float2 type; };
+template <> struct FlowOf<_Float16> { typedef f16x2_t type; };
+__device__ inline float2 nt_load2(const f16x2_t *p) {
+  const f16x2_t v = __builtin_nontemporal_load(p);
+  return make_float2((float)v.x, (float)v.y);
+}
+__device__ inline void nt_store2(float2 v, f16x2_t *p) {
+  __builtin_nontemporal_store(f16x2_t{(_Float16)v.x, (_Float16)v.y}, p);
+}
+// A half pixel of C = 3 is 6 bytes at a 2-byte aligned address: it is read as ONE 4-byte ALIGNED 8-byte
+// access that also covers the half in front of or behind it (three 2-byte accesses per pixel and tap
+// made these kernels instruction bound: 0.14 ms against 0.086 ms in f32; an 8-byte access at the
+// pixel's own, every other time misaligned, address 0.098 ms).  `guard` carries the parity of the
+// item's first half in bit 31 and, below it, the offset of the tensor's very last pixel (all ones when
+// the block's item is not the last): there the access ends with the pixel, so nothing is read past
+// the end of the tensor.
+typedef _Float16 f16x4u_t __attribute__((ext_vector_type(4), aligned(2)));
+typedef _Float16 f16x2u_t __attribute__((ext_vector_type(2), aligned(2)));
+template <int C>
+__device__ inline void load_tap(float (&r)[C], const float *base, unsigned off, unsigned) {
+  const float *p = base + off;   // pointer first, constant channel index after: the C loads merge into one dwordx2 / x3
+#pragma unroll
+  for (int c = 0; c < C; ++c) r[c] = p[c];
+}
+template <int C>
+__device__ inline void load_tap(float (&r)[C], const _Float16 *base, unsigned off, unsigned guard) {
+  if constexpr (C == 3) {
+    const unsigned sh = off == (guard & 0x7fffffffu) ? 1u : ((off + (guard >> 31)) & 1u);
+    // (signed: the first pixel of an item that starts on an odd half reads the half in front of it)
+    const f16x4u_t v = *reinterpret_cast<const f16x4u_t *>(base + ((int)off - (int)sh));
+    r[0] = (float)(sh ? v.y : v.x);
+    r[1] = (float)(sh ? v.z : v.y);
+    r[2] = (float)(sh ? v.w : v.z);
+  } else if constexpr (C == 2) {
+    const f16x2_t v = *reinterpret_cast<const f16x2_t *>(base + off);
+    r[0] = (float)v.x;
+    r[1] = (float)v.y;
+  } else {
+    r[0] = (float)base[off];
+  }
+}
+template <int C>
+__device__ inline void nt_store_px(const float (&r)[C], _Float16 *p) {
+  if constexpr (C == 3) {
+    __builtin_nontemporal_store(f16x2u_t{(_Float16)r[0], (_Float16)r[1]}, reinterpret_cast<f16x2u_t *>(p));
+    __builtin_nontemporal_store((_Float16)r[2], p + 2);
+  } else if constexpr (C == 2) {
+    __builtin_nontemporal_store(f16x2_t{(_Float16)r[0], (_Float16)r[1]}, reinterpret_cast<f16x2_t *>(p));
+  } else {
+    __builtin_nontemporal_store((_Float16)r[0], p);
+  }
+}
+
 #ifndef UNFLOW_TUNE_PPL
 #define UNFLOW_TUNE_PPL 2   // measured at B=32 384x1280 C=3: 1 -> 5.3, 2 -> 5.9, 4 -> 5.8, 8 -> 1.8 TB/s (backward_warp)
 #endif
@@ -315,6 +373,7 @@ constexpr int kFastTileH = kTileH * kPPL;        // 16 rows
 struct FastTile {
   int x, y0;          // lane's column, first row (rows y0 + 4 i)
   long long item_px;  // b * H * W
+  int b;
   bool xok;
 };
 __device__ inline FastTile fast_tile(int H, int W, int ntx, int nty) {
@@ -324,6 +383,7 @@ __device__ inline FastTile fast_tile(int H, int W, int ntx, int nty) {
   t.x = tx * kTileW + (threadIdx.x & (kTileW - 1));
   t.y0 = ty * kFastTileH + (threadIdx.x >> 6);
   t.item_px = (long long)b * H * W;
+  t.b = b;
   t.xok = t.x < W;
   return t;
 }
@@ -336,15 +396,15 @@ inline bool fast_ok(int B, int H, int W, int C) {
   return C >= 1 && C <= 3 && (long long)H * W * 3 < (1LL << 30) && tiles < (1LL << 31) && tiles > 0;
 }
 
-template <int C, bool CLAMP>   // CLAMP: image_warp (floor the flow, clamped taps); else backward_warp (zero outside)
-__global__ __launch_bounds__(kBlock) void warp_fwd_fast_kernel(const float *__restrict__ images,
-                                                               const float2 *__restrict__ flows,
-                                                               float *__restrict__ output, int H, int W, int ntx,
+template <int C, bool CLAMP, class T = float>   // CLAMP: image_warp (floor the flow, clamped taps); else backward_warp (zero outside)
+__global__ __launch_bounds__(kBlock) void warp_fwd_fast_kernel(const T *__restrict__ images,
+                                                               const typename FlowOf<T>::type *__restrict__ flows,
+                                                               T *__restrict__ output, int H, int W, int ntx,
                                                                int nty) {
   const FastTile ft = fast_tile(H, W, ntx, nty);
-  const float *base = images + ft.item_px * C;
-  const float2 *fl = flows + ft.item_px;
-  float *out = output + ft.item_px * C;
+  const T *base = images + ft.item_px * C;
+  const typename FlowOf<T>::type *fl = flows + ft.item_px;
+  T *out = output + ft.item_px * C;
   bool ok[kPPL];
   unsigned pix[kPPL];
   float2 f[kPPL];
@@ -384,17 +444,15 @@ __global__ __launch_bounds__(kBlock) void warp_fwd_fast_kernel(const float *__re
     }
   }
   float l00[kPPL][C], l01[kPPL][C], l10[kPPL][C], l11[kPPL][C];
+  // (fp16 storage, C = 3: offset of the tensor's last pixel if this block works on the last item)
+  const unsigned guard = (ft.b == (int)(gridDim.x / (unsigned)(ntx * nty)) - 1 ? (unsigned)(H * W - 1) * C : 0x7fffffffu) |
+                         ((unsigned)(ft.item_px * C) << 31);
 #pragma unroll
   for (int i = 0; i < kPPL; ++i) {
-    // pointers first, constant channel index after: the C loads of a tap merge into one dwordx2 / x3
-    const float *p00 = base + o00[i], *p01 = base + o01[i], *p10 = base + o10[i], *p11 = base + o11[i];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      l00[i][c] = p00[c];
-      l01[i][c] = p01[c];
-      l10[i][c] = p10[c];
-      l11[i][c] = p11[c];
-    }
+    load_tap<C>(l00[i], base, o00[i], guard);
+    load_tap<C>(l01[i], base, o01[i], guard);
+    load_tap<C>(l10[i], base, o10[i], guard);
+    load_tap<C>(l11[i], base, o11[i], guard);
   }
 #pragma unroll
   for (int i = 0; i < kPPL; ++i)
@@ -425,17 +483,17 @@ __global__ __launch_bounds__(kBlock) void warp_fwd_fast_kernel(const float *__re
   }
 }
 
-template <int C, bool CLAMP>   // gradient with respect to the flow
-__global__ __launch_bounds__(kBlock) void warp_bwd_flow_fast_kernel(const float *__restrict__ grad,
-                                                                    const float *__restrict__ images,
-                                                                    const float2 *__restrict__ flows,
-                                                                    float2 *__restrict__ d_flow, int H, int W, int ntx,
+template <int C, bool CLAMP, class T = float>   // gradient with respect to the flow
+__global__ __launch_bounds__(kBlock) void warp_bwd_flow_fast_kernel(const T *__restrict__ grad,
+                                                                    const T *__restrict__ images,
+                                                                    const typename FlowOf<T>::type *__restrict__ flows,
+                                                                    typename FlowOf<T>::type *__restrict__ d_flow, int H, int W, int ntx,
                                                                     int nty) {
   const FastTile ft = fast_tile(H, W, ntx, nty);
-  const float *base = images + ft.item_px * C;
-  const float *gin = grad + ft.item_px * C;
-  const float2 *fl = flows + ft.item_px;
-  float2 *dout = d_flow + ft.item_px;
+  const T *base = images + ft.item_px * C;
+  const T *gin = grad + ft.item_px * C;
+  const typename FlowOf<T>::type *fl = flows + ft.item_px;
+  typename FlowOf<T>::type *dout = d_flow + ft.item_px;
   bool ok[kPPL];
   unsigned pix[kPPL];
   float2 f[kPPL];
@@ -470,20 +528,20 @@ __global__ __launch_bounds__(kBlock) void warp_bwd_flow_fast_kernel(const float 
     }
   }
   float l00[kPPL][C], l01[kPPL][C], l10[kPPL][C], l11[kPPL][C], g[kPPL][C];
+  const unsigned guard = (ft.b == (int)(gridDim.x / (unsigned)(ntx * nty)) - 1 ? (unsigned)(H * W - 1) * C : 0x7fffffffu) |
+                         ((unsigned)(ft.item_px * C) << 31);
 #pragma unroll
   for (int i = 0; i < kPPL; ++i) {
-    // pointers first, constant channel index after: the C loads of a tap merge into one dwordx2 / x3
-    const float *p00 = base + o00[i], *p01 = base + o01[i], *p10 = base + o10[i], *p11 = base + o11[i];
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-      l00[i][c] = p00[c];
-      l01[i][c] = p01[c];
-      l10[i][c] = p10[c];
-      l11[i][c] = p11[c];
-    }
+    load_tap<C>(l00[i], base, o00[i], guard);
+    load_tap<C>(l01[i], base, o01[i], guard);
+    load_tap<C>(l10[i], base, o10[i], guard);
+    load_tap<C>(l11[i], base, o11[i], guard);
   }
 #pragma unroll
-  for (int i = 0; i < kPPL; ++i) nt_load_px<C>(g[i], gin + (size_t)pix[i] * C);
+  for (int i = 0; i < kPPL; ++i) {
+    if constexpr (std::is_same<T, float>::value) nt_load_px<C>(g[i], gin + (size_t)pix[i] * C);
+    else load_tap<C>(g[i], gin, pix[i] * C, guard);
+  }
 #pragma unroll
   for (int i = 0; i < kPPL; ++i)
 #pragma unroll
@@ -580,7 +638,14 @@ __device__ inline float gauss(float d) {   // exp(-d*d/2) through v_exp_f32
   return __builtin_amdgcn_exp2f(d * d * -0.72134752044448170368f);
 }
 
-__global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const float2 *__restrict__ flows,
+__device__ inline float2 flow_at(const float2 *p, long long i) { return p[i]; }
+__device__ inline float2 flow_at(const f16x2_t *p, long long i) {
+  const f16x2_t v = p[i];
+  return make_float2((float)v.x, (float)v.y);
+}
+
+template <class FT>   // float2, or f16x2_t (fp16 storage of the flows; the density is accumulated and written in f32)
+__global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const FT *__restrict__ flows,
                                                                          float *__restrict__ output, int H, int W) {
   __shared__ unsigned win[kWinCells];
   __shared__ int box[4];                     // min_x, min_y, -max_x, -max_y (all reduced with atomicMin)
@@ -591,14 +656,14 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const f
   const int sx = x0 + (threadIdx.x % kSX), sy = y0 + threadIdx.x / kSX;
   Window w;
   w.any = false;
-  if (sx < W && sy < H) w = splat_window(sx, sy, flows[item + (long long)sy * W + sx], H, W);
+  if (sx < W && sy < H) w = splat_window(sx, sy, flow_at(flows, item + (long long)sy * W + sx), H, W);
 
   // First guess (free for a coherent flow): a 96x48 window centred on where the
   // tile-centre pixel lands.  Only if some lane's patch misses it is the tile's
   // bounding box reduced (wave shuffles, then one LDS atomic per wave) and, when it
   // fits the LDS capacity, used as the window instead.
   const int cxp = min(x0 + kSX / 2, W - 1), cyp = min(y0 + kSY / 2, H - 1);
-  const float2 fc = flows[item + (long long)cyp * W + cxp];
+  const float2 fc = flow_at(flows, item + (long long)cyp * W + cxp);
   // clamped so that a NaN/huge centre flow still gives a usable (if useless) window
   int wx0 = (int)fminf(fmaxf(floorf((float)cxp + fc.x), -1e6f), 1e6f) - kWW / 2;
   int wy0 = (int)fminf(fmaxf(floorf((float)cyp + fc.y), -1e6f), 1e6f) - kWH / 2;
@@ -1066,6 +1131,15 @@ using namespace unflow;
     else hipLaunchKernelGGL((KERNEL<3, CLAMP>), g_, dim3(kBlock), 0, s, __VA_ARGS__, H, W, ntx_, nty_);             \
   } while (0)
 
+#define FAST_LAUNCH_F16(KERNEL, CLAMP, ...)                                                                          \
+  do {                                                                                                               \
+    const int ntx_ = (W + kTileW - 1) / kTileW, nty_ = (H + kFastTileH - 1) / kFastTileH;                            \
+    const dim3 g_((unsigned)((long long)B * ntx_ * nty_));                                                            \
+    if (C == 1) hipLaunchKernelGGL((KERNEL<1, CLAMP, _Float16>), g_, dim3(kBlock), 0, s, __VA_ARGS__, H, W, ntx_, nty_);      \
+    else if (C == 2) hipLaunchKernelGGL((KERNEL<2, CLAMP, _Float16>), g_, dim3(kBlock), 0, s, __VA_ARGS__, H, W, ntx_, nty_); \
+    else hipLaunchKernelGGL((KERNEL<3, CLAMP, _Float16>), g_, dim3(kBlock), 0, s, __VA_ARGS__, H, W, ntx_, nty_);             \
+  } while (0)
+
 #define DISPATCH_C(KERNEL, C, ...)                                                               \
   do {                                                                                           \
     switch (C) {                                                                                 \
@@ -1179,7 +1253,7 @@ extern "C" int unflow_forward_warp_fwd(const float *flows, float *output, int B,
   hipStream_t s = as_stream(stream);
   if (hipMemsetAsync(output, 0, sizeof(float) * (size_t)total, s) != hipSuccess)
     return launch_status("forward_warp_fwd memset");
-  hipLaunchKernelGGL(forward_warp_fwd_kernel, dim3((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B), dim3(kSplatThreads), 0, s,
+  hipLaunchKernelGGL(forward_warp_fwd_kernel<float2>, dim3((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B), dim3(kSplatThreads), 0, s,
                      reinterpret_cast<const float2 *>(flows), output, H, W);
   return launch_status("forward_warp_fwd");
 }
@@ -1201,6 +1275,81 @@ extern "C" int unflow_forward_warp_bwd(const float *input_grad, const float *flo
                      reinterpret_cast<const float2 *>(flows), reinterpret_cast<float2 *>(output_grad), H, W,
                      vtotal);
   return launch_status("forward_warp_bwd");
+}
+
+// ---- fp16 storage (extension, BASELINE config 5): half images / flows / gradients, f32 arithmetic.
+// C = 1, 2 or 3; 2-byte aligned tensors (4-byte for the flows).
+static int check_f16(const char *what, int B, int H, int W, int C) {
+  if (int rc = check_dims(what, B, H, W, C)) return rc;
+  if ((long long)B * H * W != 0 && !fast_ok(B, H, W, C))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "%s (fp16 storage): 1 <= channels <= 3 and H*W*3 < 2^30 required", what);
+  return UNFLOW_OK;
+}
+static bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }
+#define UNFLOW_F16_ALIGNED(WHAT, ...)                                                               \
+  do {                                                                                              \
+    const void *ptrs_[] = {__VA_ARGS__};                                                            \
+    for (const void *q_ : ptrs_)                                                                    \
+      if (!aligned4(q_)) return fail(UNFLOW_ERR_INVALID_ARGUMENT, WHAT " (fp16 storage): tensors must be 4-byte aligned"); \
+  } while (0)
+
+extern "C" int unflow_backward_warp_fwd_f16(const void *images, const void *flows, void *output, int B, int H, int W,
+                                            int C, unflow_stream_t stream) {
+  if (int rc = check_f16("backward_warp", B, H, W, C)) return rc;
+  if ((long long)B * H * W == 0) return UNFLOW_OK;
+  UNFLOW_F16_ALIGNED("backward_warp", images, flows, output);
+  hipStream_t s = as_stream(stream);
+  FAST_LAUNCH_F16(warp_fwd_fast_kernel, false, static_cast<const _Float16 *>(images), static_cast<const f16x2_t *>(flows),
+                  static_cast<_Float16 *>(output));
+  return launch_status("backward_warp_fwd_f16");
+}
+
+extern "C" int unflow_backward_warp_bwd_f16(const void *input_grad, const void *images, const void *flows,
+                                            void *output_grad, int B, int H, int W, int C, unflow_stream_t stream) {
+  if (int rc = check_f16("backward_warp_grad", B, H, W, C)) return rc;
+  if ((long long)B * H * W == 0) return UNFLOW_OK;
+  UNFLOW_F16_ALIGNED("backward_warp_grad", input_grad, images, flows, output_grad);
+  hipStream_t s = as_stream(stream);
+  FAST_LAUNCH_F16(warp_bwd_flow_fast_kernel, false, static_cast<const _Float16 *>(input_grad),
+                  static_cast<const _Float16 *>(images), static_cast<const f16x2_t *>(flows),
+                  static_cast<f16x2_t *>(output_grad));
+  return launch_status("backward_warp_bwd_f16");
+}
+
+extern "C" int unflow_image_warp_fwd_f16(const void *im, const void *flow, void *warped, int B, int H, int W, int C,
+                                         unflow_stream_t stream) {
+  if (int rc = check_f16("image_warp", B, H, W, C)) return rc;
+  if ((long long)B * H * W == 0) return UNFLOW_OK;
+  UNFLOW_F16_ALIGNED("image_warp", im, flow, warped);
+  hipStream_t s = as_stream(stream);
+  FAST_LAUNCH_F16(warp_fwd_fast_kernel, true, static_cast<const _Float16 *>(im), static_cast<const f16x2_t *>(flow),
+                  static_cast<_Float16 *>(warped));
+  return launch_status("image_warp_fwd_f16");
+}
+
+extern "C" int unflow_image_warp_bwd_flow_f16(const void *grad, const void *im, const void *flow, void *d_flow, int B,
+                                              int H, int W, int C, unflow_stream_t stream) {
+  if (int rc = check_f16("image_warp_grad", B, H, W, C)) return rc;
+  if ((long long)B * H * W == 0) return UNFLOW_OK;
+  UNFLOW_F16_ALIGNED("image_warp_grad", grad, im, flow, d_flow);
+  hipStream_t s = as_stream(stream);
+  FAST_LAUNCH_F16(warp_bwd_flow_fast_kernel, true, static_cast<const _Float16 *>(grad), static_cast<const _Float16 *>(im),
+                  static_cast<const f16x2_t *>(flow), static_cast<f16x2_t *>(d_flow));
+  return launch_status("image_warp_bwd_flow_f16");
+}
+
+extern "C" int unflow_forward_warp_fwd_f16(const void *flows, float *output, int B, int H, int W,
+                                           unflow_stream_t stream) {
+  if (int rc = check_dims("forward_warp", B, H, W, 2)) return rc;
+  const long long total = (long long)B * H * W;
+  if (total == 0) return UNFLOW_OK;
+  if (!aligned4(flows)) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "forward_warp (fp16 storage): flows must be 4-byte aligned");
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(output, 0, sizeof(float) * (size_t)total, s) != hipSuccess)
+    return launch_status("forward_warp_fwd_f16 memset");
+  hipLaunchKernelGGL(forward_warp_fwd_kernel<f16x2_t>, dim3((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B),
+                     dim3(kSplatThreads), 0, s, static_cast<const f16x2_t *>(flows), output, H, W);
+  return launch_status("forward_warp_fwd_f16");
 }
 
 extern "C" int unflow_downsample_fwd(const float *images, float *output, int B, int H, int W, int C, int scale,

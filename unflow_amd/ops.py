@@ -324,6 +324,62 @@ def correlation_fp16(first, second, kernel_size=1, max_displacement=20, pad=20, 
     return _CorrelationFP16.apply(first, second, (kernel_size, max_displacement, pad, stride_1, stride_2))
 
 
+class _WarpFP16(torch.autograd.Function):
+    """backward_warp / image_warp with fp16 storage: flow gradient only (the reference registers no
+    image gradient for backward_warp either; image_warp's is an f32 scatter-add)."""
+
+    @staticmethod
+    def forward(ctx, images, flows, clamp):
+        images, flows = _half(images, "images"), _half(flows, "flows")
+        _require_rank4(images, "images")
+        _check_flow(images, flows)
+        B, H, W, C = images.shape
+        out = torch.empty_like(images)
+        fn = _lib.load().unflow_image_warp_fwd_f16 if clamp else _lib.load().unflow_backward_warp_fwd_f16
+        with torch.cuda.device(images.device):
+            _lib.check(fn(_hp(images), _hp(flows), _hp(out), B, H, W, C, _stream()))
+        ctx.save_for_backward(images, flows)
+        ctx.clamp = clamp
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        images, flows = ctx.saved_tensors
+        grad = _half(grad, "grad")
+        B, H, W, C = images.shape
+        d_flow = torch.empty_like(flows)
+        fn = _lib.load().unflow_image_warp_bwd_flow_f16 if ctx.clamp else _lib.load().unflow_backward_warp_bwd_f16
+        with torch.cuda.device(images.device):
+            _lib.check(fn(_hp(grad), _hp(images), _hp(flows), _hp(d_flow), B, H, W, C, _stream()))
+        return None, d_flow, None
+
+
+def backward_warp_fp16(images, flows):
+    """Extension (BASELINE config 5): ``backward_warp`` on float16 tensors -- fp16 in HBM, the f32
+    kernel's arithmetic, one rounding to half per output; differentiable in the flows.  1 <= C <= 3."""
+    return _WarpFP16.apply(images, flows, False)
+
+
+def image_warp_fp16(im, flow):
+    """Extension (BASELINE config 5): ``image_warp`` (core/image_warp.py:4) on float16 tensors;
+    differentiable in the flow (the image gradient needs the float32 op).  1 <= C <= 3."""
+    return _WarpFP16.apply(im, flow, True)
+
+
+def forward_warp_fp16(flows):
+    """Extension (BASELINE config 5): ``forward_warp`` of float16 flows; the density comes back in
+    float32, the precision it is accumulated in.  Not differentiable."""
+    flows = _half(flows, "flows")
+    _require_rank4(flows, "flows")
+    if flows.shape[3] != 2:
+        raise ValueError("flows must have 2 channels")
+    B, H, W, _ = flows.shape
+    out = torch.empty((B, H, W, 1), device=flows.device, dtype=torch.float32)
+    with torch.cuda.device(flows.device):
+        _lib.check(_lib.load().unflow_forward_warp_fwd_f16(_hp(flows), ctypes.c_void_p(out.data_ptr()), B, H, W, _stream()))
+    return out
+
+
 def correlation_with_padded(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1,
                             stride_2=2):
     """All three outputs of the reference op (``_correlation_module.correlation``):
