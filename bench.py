@@ -531,7 +531,7 @@ def main():
                         "(ops.correlation_bidirectional, DESIGN.md 4.1)",
                 "ms_per_step": dt_bidir / args.steps * 1e3, "value": pairs / dt_bidir, "unit": "image-pairs/s"}
             out["kitti_config_step"] = kitti_config_step(wl)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: the other ranks would idle at the barrier
             out["cpu_baseline"] = cpu_baseline(wl, runs=args.cpu_runs)
         print(json.dumps(out))
         sys.stdout.flush()
