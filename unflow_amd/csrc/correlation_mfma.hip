@@ -91,6 +91,11 @@ __device__ inline void dma(__amdgpu_buffer_rsrc_t r, float *lds_dst, unsigned vo
   else __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_dst, 4, (int)voff, soff, 0, 0);
 }
 
+// Workgroup barrier that publishes an LDS-DMA stage.  Written out: the compiler's wait-count
+// insertion does not know that a buffer_load ... lds has a side in LDS -- depending on where it
+// stands a plain __syncthreads() came out with vmcnt(9) or with no vmcnt wait at all.
+__device__ inline void dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // XCD-aware block order: hardware deals consecutive block ids round-robin to the
 // 8 XCDs; remap so that each XCD walks a contiguous range of regions (one image
 // pair's windows overlap heavily and then share that XCD's L2).
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
   const int nchunks = (C + KC - 1) / KC;
   st.bind(in0, in1, item, 0, C, plane);
   st.template issue_range<0, St::PER_WAVE>(lds);
-  __syncthreads();   // drains the DMA (vmcnt(0)) and publishes the stage
+  dma_barrier();   // drains the DMA (vmcnt(0)) and publishes the stage
 
   constexpr int GROUPS = (KC / 4) * TQ;                              // MFMA groups per chunk (12)
   // DMA pieces issued after each group: all of them in the first half of the
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_fwd_kernel(const float 
       };
       group(Int<0>{}); group(Int<1>{}); group(Int<2>{}); group(Int<3>{}); group(Int<4>{}); group(Int<5>{});
     }
-    __syncthreads();
+    dma_barrier();
   }
 
   // ---- epilogue: regroup G[p][q] by displacement d = q - p through LDS ----
@@ -583,8 +588,12 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
     st.store(lds);
   } else {
     st.template issue_range<0, St::PER_WAVE>(lds);
+    if (nchunks > 1) {                           // f32: the DMA runs two chunks ahead (see the loop)
+      st.bind(in0, in1, item, KC, C, plane);
+      st.template issue_range<0, St::PER_WAVE>(lds + STAGEH);
+    }
   }
-  __syncthreads();
+  dma_barrier();
 
   constexpr int GROUPS = (KC / 4) * TQH;                             // 6 MFMA groups per chunk
 #ifdef UNFLOW_TUNE_STAMPS
@@ -597,12 +606,21 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
 #endif
   for (int ch = 0; ch < nchunks; ++ch) {
     UNFLOW_STAMP(ch, 0);
-    const float *cur = lds + (ch & 1) * STAGEH;
+    float *cur = lds + (ch & 1) * STAGEH;
     float *nxt = lds + ((ch + 1) & 1) * STAGEH;
-    const bool more = ch + 1 < nchunks;
-    if (more) {
-      st.bind(in0, in1, item, (ch + 1) * KC, C, plane);
-      if constexpr (F16) st.load();            // lands in registers while this chunk computes
+    // f32: the chunk's barrier stands in front of the MFMAs of its SECOND K-step, behind that
+    // K-step's fragment reads -- the last reads of this stage.  When it opens, 18 MFMAs are ready to
+    // issue (a barrier at the end of the chunk was followed by 19 LDS reads with an empty matrix
+    // pipe), chunk ch + 1 has landed in the other stage, and this stage takes the DMA of chunk
+    // ch + 2, issued between the MFMA groups that follow.
+    // fp16 storage: the next chunk is loaded into registers at the top and written to the other
+    // stage at the end of the chunk, with the barrier behind it.
+    const bool more = F16 ? ch + 1 < nchunks : ch + 2 < nchunks;
+    if constexpr (F16) {
+      if (more) {
+        st.bind(in0, in1, item, (ch + 1) * KC, C, plane);
+        st.load();                               // lands in registers while this chunk computes
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < KC / 4; ++kk) {
@@ -611,6 +629,14 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
       float b[NTH];
 #pragma unroll
       for (int t = 0; t < NTH; ++t) b[t] = bp[(t / TQ) * 4 * ROWF + (t % TQ) * 4 * S];
+      if constexpr (!F16) {
+        if (kk == KC / 4 - 1) {
+          UNFLOW_STAMP(ch, 2);
+          dma_barrier();   // (a plain __syncthreads() came out as lgkmcnt(0) alone here)
+          UNFLOW_STAMP(ch, 3);
+          if (more) st.bind(in0, in1, item, (ch + 2) * KC, C, plane);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       auto group = [&](auto G) {
         constexpr int g = decltype(G)::value;
@@ -620,14 +646,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[t], acc[t], 0, 0, 0);
         }
         if constexpr (!F16) {
-          constexpr int PER_GROUP = (2 * St::PER_WAVE + GROUPS - 1) / GROUPS;   // all DMA in the first K-step
+          constexpr int PER_GROUP = (St::PER_WAVE + TQH - 1) / TQH;   // all DMA behind the barrier, in the second K-step
 #ifdef UNFLOW_TUNE_FWD_NODMA
           if (more && C < 0) {
 #else
           if (more) {
 #endif
-            if (kk == 0) st.template issue_range<g * PER_GROUP, PER_GROUP>(nxt);
-            else st.template issue_range<(TQH + g) * PER_GROUP, PER_GROUP>(nxt);
+            if (kk == KC / 4 - 1) st.template issue_range<g * PER_GROUP, PER_GROUP>(cur);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -636,10 +661,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
     }
     if constexpr (F16) {
       if (more) st.store(nxt);
+      UNFLOW_STAMP(ch, 2);
+      __syncthreads();
+      UNFLOW_STAMP(ch, 3);
     }
-    UNFLOW_STAMP(ch, 2);
-    __syncthreads();
-    UNFLOW_STAMP(ch, 3);
   }
   UNFLOW_STAMP(STAMP_ROWS, 1);   // epilogue starts
 
@@ -961,7 +986,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
   } else {
     issue_row(0, lds);
   }
-  __syncthreads();
+  dma_barrier();
   for (int w = 0; w < hs; ++w) {
     const float *cur = lds + (w & 1) * SW_STAGE;
     float *nxt = lds + ((w + 1) & 1) * SW_STAGE;
@@ -1010,7 +1035,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
     load_ab(Int<0>{});
     kstep(Int<0>{}); kstep(Int<1>{}); kstep(Int<2>{}); kstep(Int<3>{}); kstep(Int<4>{}); kstep(Int<5>{});
     if (F16 && more) store_row(nxt);
-    __syncthreads();
+    dma_barrier();
 
     // ---- tiles whose last window row was w: regroup through LDS to
     // [channel][row 4][16 columns] and store 64-byte row segments.
