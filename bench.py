@@ -86,7 +86,7 @@ def spawn_ranks(args):
     if not args.dry:
         import torch
         have = torch.cuda.device_count()          # does not create a HIP context
-        if have < n:
+        if have < n and not os.environ.get("UNFLOW_BENCH_SHARE_GPU"):
             print("bench.py: --gpus %d but only %d visible" % (n, have), file=sys.stderr)
             return 2
     port = free_port()
@@ -430,7 +430,10 @@ def main():
     if world != max(args.gpus, 1) and rank == 0:
         print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus=%d"
               % (args.gpus, world, world), file=sys.stderr)
-    dev = torch.device("cuda", local_rank)
+    # UNFLOW_BENCH_SHARE_GPU=1: rehearsal of the N-rank path on a one-GPU box (all ranks on cuda:0, use
+    # --backend gloo: RCCL refuses two ranks on one device); the line then says so and is no measurement
+    shared = bool(os.environ.get("UNFLOW_BENCH_SHARE_GPU"))
+    dev = torch.device("cuda", 0 if shared else local_rank)
     torch.cuda.set_device(dev)
 
     wl = Workload(args.batch, dev, seed=1234 + rank, global_batch=args.batch * world)
@@ -499,7 +502,8 @@ def main():
                                    "kernels, 2 forward_warp + sym term, 2 ternary 7x7) fwd+bwd" % args.batch,
                        "global_batch": args.batch * world, "height": H, "width": W,
                        "parallelism": "batch-sharded x%d (one process per GPU), all-reduce of loss + 156.7 MB grad buffer" % world,
-                       "world_size": world, "backend": dist.get_backend() if world > 1 else None},
+                       "world_size": world, "backend": dist.get_backend() if world > 1 else None,
+                       **({"rehearsal_all_ranks_on_one_gpu": True} if shared else {})},
             "roofline": {"bound": "mfma",
                          "kernel": "correlation backward: corr_mfma_bwd2_kernel, both gradient launches of one call",
                          "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",

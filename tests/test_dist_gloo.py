@@ -112,3 +112,20 @@ def test_bench_launcher_reports_a_failing_rank():
     """A rank that dies takes the launch down with a non-zero status (no hang, no silent success)."""
     out, lines = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", env_extra={"UNFLOW_BENCH_FAIL_RANK": "1"})
     assert out.returncode != 0 and not lines
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_the_gpu_rehearsal():
+    """The N = 2 path of bench.py with real GPU work: two ranks (here both on cuda:0 -- a rehearsal, flagged
+    as such in the line -- over gloo, because RCCL refuses two ranks on one device), the barrier /
+    max-over-ranks timing, the all-reduce of loss and gradient buffer, one line from rank 0 with the
+    whole-job value."""
+    out, lines = _run_bench("--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--batch", "4",
+                            "--no-cpu-baseline", "--no-extras", env_extra={"UNFLOW_BENCH_SHARE_GPU": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["config"]["world_size"] == 2 and line["config"]["global_batch"] == 8
+    assert line["config"]["rehearsal_all_ranks_on_one_gpu"] is True
+    assert line["value"] > 0 and abs(line["value"] - 8 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert "cpu_baseline" not in line and line["roofline"]["bound"] == "mfma"
