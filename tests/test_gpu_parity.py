@@ -864,3 +864,47 @@ def test_stream_copy_probe(dev):
                                               ctypes.c_size_t(a.numel() * 4 - 16), None))
     torch.cuda.synchronize()
     assert torch.equal(a[:-4], b[:-4]) and float(b[-4:].abs().max()) == 0.0
+
+
+def _offset_by_one_float(t):
+    """The same values at an address that is 4-byte but not 8- or 16-byte aligned (a view one float into a
+    larger allocation; torch allocations themselves are 512-byte aligned)."""
+    big = torch.empty(t.numel() + 1, device=t.device, dtype=t.dtype)
+    view = big[1:].view(t.shape)
+    view.copy_(t)
+    assert view.data_ptr() % 8 == 4 and view.is_contiguous()
+    return view
+
+
+def test_unaligned_tensors_take_the_same_results(dev):
+    """Inputs that are only 4-byte aligned (a slice of a larger buffer): the vectorised paths -- LDS-DMA and
+    float4 stores of the correlation, the vector row loads of downsample, the float4 output of the stacked
+    block -- are gated on alignment and fall back; results are the same as on aligned tensors."""
+    from unflow_amd import flownet, losses, ops
+    from unflow_amd.image_warp import image_warp
+    g = torch.Generator(device=dev).manual_seed(3)
+    f0 = torch.randn((2, 128, 12, 16), device=dev, generator=g)
+    f1 = torch.randn((2, 128, 12, 16), device=dev, generator=g)
+    top = torch.randn((2, 441, 12, 16), device=dev, generator=g)
+    c = ops.correlation(f0, f1)
+    g0, g1 = ops.correlation_grad(top, f0, f1)
+    u0, u1, utop = _offset_by_one_float(f0), _offset_by_one_float(f1), _offset_by_one_float(top)
+    torch.testing.assert_close(ops.correlation(u0, u1), c, rtol=1e-5, atol=1e-6)      # generic kernels: another summation order
+    h0, h1 = ops.correlation_grad(utop, u0, u1)
+    torch.testing.assert_close(h0, g0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(h1, g1, rtol=1e-5, atol=1e-6)
+    im = torch.rand((2, 20, 64, 3), device=dev, generator=g)
+    flow = torch.randn((2, 20, 64, 2), device=dev, generator=g) * 4
+    uim, uflow = _offset_by_one_float(im), _offset_by_one_float(flow)
+    assert torch.equal(image_warp(uim, uflow), image_warp(im, flow))
+    assert torch.equal(ops.backward_warp(uim, uflow), ops.backward_warp(im, flow))
+    assert torch.equal(ops.downsample(uim, 2), ops.downsample(im, 2))
+    torch.testing.assert_close(ops.forward_warp(uflow), ops.forward_warp(flow), rtol=1e-6, atol=1e-6)
+    mask = (torch.rand((2, 20, 64, 1), device=dev, generator=g) > 0.2).float()
+    im2 = torch.rand((2, 20, 64, 3), device=dev, generator=g)
+    a = losses.ternary_loss(uim, _offset_by_one_float(im2), _offset_by_one_float(mask), max_distance=3)
+    b = losses.ternary_loss(im, im2, mask, max_distance=3)
+    torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
+    lr = torch.randn((2, 5, 16, 2), device=dev, generator=g)
+    assert torch.equal(flownet.stacked_inputs(uim, _offset_by_one_float(im2), _offset_by_one_float(lr)),
+                       flownet.stacked_inputs(im, im2, lr))
