@@ -297,6 +297,12 @@ def test_warps_fp16_storage(oracle_mod, dev, B, H, W, C):
         ops.image_warp_fp16(torch.from_numpy(im32).to(dev), torch.from_numpy(flow).to(dev))
     with pytest.raises(ValueError, match="channels"):
         ops.image_warp_fp16(torch.zeros((1, 4, 4, 5), dtype=torch.float16, device=dev), torch.zeros((1, 4, 4, 2), dtype=torch.float16, device=dev))
+    # a half tensor at an odd half (2-byte aligned only) is refused, not read with 4-byte accesses
+    big = torch.zeros(B * H * W * 2 + 1, dtype=torch.float16, device=dev)
+    odd = big[1:].view(B, H, W, 2)
+    assert odd.data_ptr() % 4 == 2
+    with pytest.raises(ValueError, match="4-byte aligned"):
+        ops.image_warp_fp16(torch.from_numpy(im).to(dev), odd)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 40, 70), (1, 7, 130)])
