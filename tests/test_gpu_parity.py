@@ -418,6 +418,31 @@ def test_forward_warp_vs_oracle(oracle_mod, dev, B, H, W):
     close(f.grad, oracle_mod.forward_warp_grad(g, flow), 1e-5, 1e-5)
 
 
+def test_forward_warp_everything_lands_on_one_pixel(oracle_mod, dev):
+    """Worst case of the splat's 32-bit fixed-point LDS window (2^-21 granule, at most 1024 source pixels per
+    window): every pixel of a 128x32 image -- four full 64x16 tiles -- flows to ONE target pixel with weight
+    exp(0) = 1, i.e. each tile adds 1024 * 2^21 = 2^31 to one cell.  The density there is the pixel count."""
+    from unflow_amd import ops
+    H, W = 32, 128
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float32)
+    flow = np.stack([70.0 - xs, 9.0 - ys], axis=-1)[None]          # x + u = 70, y + v = 9 for every pixel
+    got = N(ops.forward_warp(T(flow, dev)))[0, :, :, 0]
+    # exact: 4096 identical 9x9 Gaussians around (9, 70), clipped to the image
+    exact = np.zeros((H, W))
+    for dy in range(-4, 5):
+        for dx in range(-4, 5):
+            if 0 <= 9 + dy < H and 0 <= 70 + dx < W:
+                exact[9 + dy, 70 + dx] = H * W * np.exp(-(dx * dx + dy * dy) / 2.0)
+    assert got[9, 70] == float(H * W)                               # 4 x 2^31 window units, no overflow, no rounding
+    # a contribution is rounded to 2^-21 (4.8e-7): at most 2.4e-7 * 4096 = 1e-3 off per cell
+    np.testing.assert_allclose(got, exact, rtol=1e-6, atol=1.1e-3)
+    # the oracle adds 4096 floats one after the other like the reference's float atomicAdd: its own rounding
+    # (~sqrt(N) ulp(4096) = 0.03) is what separates it from the exact value, not the kernel
+    want = oracle_mod.forward_warp(flow.astype(np.float32))[0, :, :, 0]
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1.1e-3)
+    assert np.abs(got - exact).max() <= np.abs(want - exact).max() + 1.1e-3
+
+
 def test_forward_warp_zero_flow_analytic(dev):
     from unflow_amd import ops
     out = N(ops.forward_warp(torch.zeros((1, 12, 12, 2), device=dev)))
