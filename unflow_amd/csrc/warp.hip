@@ -638,6 +638,17 @@ __device__ inline float gauss(float d) {   // exp(-d*d/2) through v_exp_f32
   return __builtin_amdgcn_exp2f(d * d * -0.72134752044448170368f);
 }
 
+#ifdef UNFLOW_TUNE_FW_STAMPS
+// Diagnostic build only (tools/stamps_fwarp.py): shader-clock stamps of the splat's phases for 64
+// workgroups (waves 0 and 15), read back through unflow_debug_read_fw_stamps().  [64 blocks][2 waves][8]
+__device__ unsigned long long g_fw_stamps[64 * 2 * 8];
+#define UNFLOW_FW_STAMP(I)                                                                                  \
+  do {                                                                                                      \
+    if (fw_slot >= 0 && (threadIdx.x & 63) == 0) g_fw_stamps[fw_slot * 8 + (I)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define UNFLOW_FW_STAMP(I) do {} while (0)
+#endif
 __device__ inline float2 flow_at(const float2 *p, long long i) { return p[i]; }
 __device__ inline float2 flow_at(const f16x2_t *p, long long i) {
   const f16x2_t v = p[i];
@@ -652,6 +663,17 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
   const int x0 = blockIdx.x * kSX, y0 = blockIdx.y * kSY;
   const long long item = (long long)blockIdx.z * H * W;
   float *out = output + item;
+#ifdef UNFLOW_TUNE_FW_STAMPS
+  int fw_slot = -1;
+  {
+    // item 5, tile rows 8..11, tile columns 4..19: 64 interior tiles in the middle of the launch
+    const int wv = threadIdx.x >> 6;
+    if (blockIdx.z == 5 && blockIdx.y >= 8 && blockIdx.y < 12 && blockIdx.x >= 4 && blockIdx.x < 20 && (wv == 0 || wv == 15))
+      fw_slot = (((int)blockIdx.y - 8) * 16 + ((int)blockIdx.x - 4)) * 2 + (wv == 15);
+  }
+  const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();   // constant 100 MHz: calibrates the shader clock
+#endif
+  UNFLOW_FW_STAMP(0);
 
   const int sx = x0 + (threadIdx.x % kSX), sy = y0 + threadIdx.x / kSX;
   Window w;
@@ -670,7 +692,10 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
   int ww = kWW, wh = kWH;
   const bool miss = w.any && !(w.min_x >= wx0 && w.max_x < wx0 + kWW && w.min_y >= wy0 && w.max_y < wy0 + kWH);
   if (threadIdx.x < 4) box[threadIdx.x] = 0x7fffffff;
-  if (__syncthreads_or(miss)) {
+  UNFLOW_FW_STAMP(1);                        // flows loaded, window guessed
+  const bool any_miss = __syncthreads_or(miss);
+  UNFLOW_FW_STAMP(2);
+  if (any_miss) {
     int b0 = w.any ? w.min_x : 0x7fffffff, b1 = w.any ? w.min_y : 0x7fffffff;
     int b2 = w.any ? -w.max_x : 0x7fffffff, b3 = w.any ? -w.max_y : 0x7fffffff;
 #pragma unroll
@@ -698,6 +723,7 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
   const int cells = ww * wh;
   for (int i = threadIdx.x; i < cells; i += kSplatThreads) win[i] = 0u;
   __syncthreads();
+  UNFLOW_FW_STAMP(3);                        // window zeroed
 
   if (w.any) {
     float ex[9];
@@ -735,7 +761,9 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
       }
     }
   }
+  UNFLOW_FW_STAMP(4);                        // taps issued
   __syncthreads();
+  UNFLOW_FW_STAMP(5);
   // flush: wave r takes window rows r, r+16, ...; lanes walk the row (no runtime division)
   for (int ly = threadIdx.x >> 6; ly < wh; ly += kSplatThreads / 64) {
     const int gy = wy0 + ly;
@@ -746,6 +774,10 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
       if (v != 0u && gx >= 0 && gx < W) unsafeAtomicAdd(out + (long long)gy * W + gx, (float)v * kUnfix);
     }
   }
+  UNFLOW_FW_STAMP(6);                        // flush issued
+#ifdef UNFLOW_TUNE_FW_STAMPS
+  if (fw_slot >= 0 && (threadIdx.x & 63) == 0) g_fw_stamps[fw_slot * 8 + 7] = __builtin_amdgcn_s_memrealtime() - rt0;
+#endif
 }
 
 // Gradient of the splat with the tile's window of input_grad staged in LDS: the same
@@ -1351,6 +1383,13 @@ extern "C" int unflow_forward_warp_fwd_f16(const void *flows, float *output, int
                      dim3(kSplatThreads), 0, s, static_cast<const f16x2_t *>(flows), output, H, W);
   return launch_status("forward_warp_fwd_f16");
 }
+
+#ifdef UNFLOW_TUNE_FW_STAMPS
+extern "C" int unflow_debug_read_fw_stamps(void *dst, size_t bytes) {
+  const size_t n = sizeof(unflow::g_fw_stamps) < bytes ? sizeof(unflow::g_fw_stamps) : bytes;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(unflow::g_fw_stamps), n, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int unflow_downsample_fwd(const float *images, float *output, int B, int H, int W, int C, int scale,
                                      unflow_stream_t stream) {
