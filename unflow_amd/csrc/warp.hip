@@ -785,7 +785,7 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
 // bounding box when it fits 60 KB); each lane then reads its 9x9 patch from LDS instead
 // of issuing 81 global loads (9 dependent rounds of 9).  Patches outside the staged
 // window fall back to global loads.
-__global__ __launch_bounds__(kSplatThreads) void forward_warp_bwd_tiled_kernel(const float *__restrict__ input_grad,
+__global__ __launch_bounds__(kSplatThreads, 8) void forward_warp_bwd_tiled_kernel(const float *__restrict__ input_grad,
                                                                                const float2 *__restrict__ flows,
                                                                                float2 *__restrict__ output_grad,
                                                                                int H, int W) {
