@@ -187,6 +187,10 @@ class Workload:
         from unflow_amd import dist as udist
         from unflow_amd import ops
         torch = self.torch
+        # N > 1: the gradient buffer's all-reduce runs on RCCL's stream while the step computes (a
+        # bucketed data-parallel trainer overlaps it with the backward pass) and is waited for -- by the
+        # stream, not the host -- before the step ends
+        pending = self.grad_buffer.all_reduce_async() if world > 1 else None
         with torch.no_grad():
             if bidirectional:
                 # extension: corr(b, a) is a bit-exact re-indexing of corr(a, b), and one
@@ -204,7 +208,8 @@ class Workload:
         loss = ls["ternary"].detach()
         if world > 1:    # the reference's average_gradients (core/train.py:446-480) as two RCCL all-reduces
             loss = udist.reduce_losses({"ternary": loss})["ternary"]
-            self.grad_buffer.all_reduce()
+            if pending is not None:
+                pending.wait()
         return loss, (c_fw, c_bw, g_fw, g_bw)
 
     def composed_loss(self):
@@ -501,7 +506,7 @@ def main():
                                    "[B,256,48,160] + level-0 compute_losses (4 image_warp evaluated inside the census and fb-occlusion "
                                    "kernels, 2 forward_warp + sym term, 2 ternary 7x7) fwd+bwd" % args.batch,
                        "global_batch": args.batch * world, "height": H, "width": W,
-                       "parallelism": "batch-sharded x%d (one process per GPU), all-reduce of loss + 156.7 MB grad buffer" % world,
+                       "parallelism": "batch-sharded x%d (one process per GPU), all-reduce of loss + 156.7 MB grad buffer (overlapped with the step's compute)" % world,
                        "world_size": world, "backend": dist.get_backend() if world > 1 else None,
                        **({"rehearsal_all_ranks_on_one_gpu": True} if shared else {})},
             "roofline": {"bound": "mfma",

@@ -83,3 +83,11 @@ class FlatGradBuffer:
     def all_reduce(self):
         all_reduce_sum_(self.buffer)
         return self.buffer
+
+    def all_reduce_async(self):
+        """Starts the SUM all-reduce on the collective's own stream and returns a handle whose ``wait()``
+        makes the current stream wait for it (no host synchronisation) -- the way a bucketed data-parallel
+        trainer overlaps its gradient exchange with the backward pass.  None for a single process."""
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            return dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, async_op=True)
+        return None
