@@ -72,6 +72,25 @@ def test_correlation_gradient_adjoint_cfg2(dev):
         assert abs(float(rhs)) > 0
 
 
+def test_correlation_is_deterministic_cfg2(dev):
+    """The MFMA kernels stage their operands by LDS-DMA behind hand-written barriers: a barrier that does not
+    wait for the DMA is a race that shows as run-to-run differences at full size (one such was found in
+    round 2).  Forward and both gradients, repeated with allocator churn in between, must agree bitwise."""
+    from unflow_amd import ops
+    g = gen(dev, 21)
+    f0 = torch.randn((8, C8, H8, W8), device=dev, generator=g)
+    f1 = torch.randn((8, C8, H8, W8), device=dev, generator=g)
+    top = torch.randn((8, 441, H8, W8), device=dev, generator=g)
+    c0 = ops.correlation(f0, f1)
+    g0, g1 = ops.correlation_grad(top, f0, f1)
+    for i in range(4):
+        junk = torch.full((16 * 1024 * 1024,), float(i), device=dev)
+        del junk
+        assert torch.equal(ops.correlation(f0, f1), c0)
+        a, b = ops.correlation_grad(top, f0, f1)
+        assert torch.equal(a, g0) and torch.equal(b, g1)
+
+
 def test_correlation_full_size_sample_vs_oracle(oracle_mod, dev):
     """One full-size pair against the CPU oracle (about 3 s of CPU)."""
     from unflow_amd import ops
