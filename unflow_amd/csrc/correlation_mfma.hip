@@ -595,7 +595,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
   }
   dma_barrier();
 
-  constexpr int GROUPS = (KC / 4) * TQH;                             // 6 MFMA groups per chunk
 #ifdef UNFLOW_TUNE_STAMPS
   int stamp_slot = -1;           // workgroups 0..3 and 1000..1003, waves 0 and 4
   {
