@@ -393,6 +393,97 @@ def compute_losses(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion=
     return losses, aux
 
 
+def compute_losses_grad(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occlusion="",
+                        data_max_distance=1, weights=None):
+    """d(sum_k weights[k] * losses[k]) / d(flow_fw, flow_bw) of compute_losses (losses.py:16-87),
+    composed the way TF's autodiff walks the graph:
+
+    * ``ternary``, ``photo``, ``grad`` reach a flow through ``image_warp``'s flow gradient of the
+      warped image (im1 / im2 are inputs, not variables);
+    * ``fb``: ``flow_diff_fw = flow_fw + image_warp(flow_bw, flow_fw)`` (losses.py:38-41), so the
+      charbonnier gradient g goes to flow_fw directly AND through the warp's flow gradient, and to
+      flow_bw through the warp's image gradient (the scatter-add of tf.gather); mirrored for bw;
+    * ``smooth_1st`` / ``smooth_2nd`` act on the flows themselves;
+    * ``occ`` and ``sym`` are built from ``tf.cast(... > ...)`` maps only (losses.py:28-29,48-49,
+      51-65): no gradient; the masks are constants for every other term for the same reason.
+
+    Returns (d_flow_fw, d_flow_bw, losses)."""
+    weights = dict(weights or {})
+    im1, im2, flow_fw, flow_bw = _f32(im1), _f32(im2), _f32(flow_fw), _f32(flow_bw)
+    losses, aux = compute_losses(im1, im2, flow_fw, flow_bw, border_mask, mask_occlusion, data_max_distance)
+    d_fw = np.zeros_like(flow_fw, dtype=np.float64)
+    d_bw = np.zeros_like(flow_bw, dtype=np.float64)
+
+    def through_warp(g_warped, im, flow):
+        return image_warp_grad(g_warped, im, flow, want_im=False)[1]
+
+    for k, wgt in weights.items():
+        if not wgt:
+            continue
+        w = np.float32(wgt)
+        if k == "ternary":
+            g2 = ternary_loss_grad(im1, aux["im2_warped"], aux["mask_fw"], data_max_distance)
+            g1 = ternary_loss_grad(im2, aux["im1_warped"], aux["mask_bw"], data_max_distance)
+            d_fw += w * through_warp(g2, im2, flow_fw)
+            d_bw += w * through_warp(g1, im1, flow_bw)
+        elif k == "photo":
+            # photometric_loss(im1 - im2_warped, mask): d/d im2_warped = -dcharb (losses.py:24,198-199)
+            g2 = -charbonnier_loss_grad(im1 - aux["im2_warped"], aux["mask_fw"], beta=255)
+            g1 = -charbonnier_loss_grad(im2 - aux["im1_warped"], aux["mask_bw"], beta=255)
+            d_fw += w * through_warp(g2, im2, flow_fw)
+            d_bw += w * through_warp(g1, im1, flow_bw)
+        elif k == "grad":
+            g2 = gradient_loss_grad(im1, aux["im2_warped"], aux["mask_fw"])
+            g1 = gradient_loss_grad(im2, aux["im1_warped"], aux["mask_bw"])
+            d_fw += w * through_warp(g2, im2, flow_fw)
+            d_bw += w * through_warp(g1, im1, flow_bw)
+        elif k in ("smooth_1st", "smooth_2nd"):
+            order = 1 if k == "smooth_1st" else 2
+            d_fw += w * smoothness_loss_grad(flow_fw, order)
+            d_bw += w * smoothness_loss_grad(flow_bw, order)
+        elif k == "fb":
+            g_fw = charbonnier_loss_grad(aux["flow_diff_fw"], aux["mask_fw"])
+            g_bw = charbonnier_loss_grad(aux["flow_diff_bw"], aux["mask_bw"])
+            to_bw, via_fw = image_warp_grad(g_fw, flow_bw, flow_fw)      # flow_bw is the warped "image"
+            to_fw, via_bw = image_warp_grad(g_bw, flow_fw, flow_bw)
+            d_fw += w * (g_fw.astype(np.float64) + via_fw + to_fw)
+            d_bw += w * (g_bw.astype(np.float64) + via_bw + to_bw)
+        elif k in ("occ", "sym"):
+            pass
+        else:
+            raise KeyError(k)
+    return d_fw.astype(np.float32), d_bw.astype(np.float32), losses
+
+
+def pyramid_loss_grad(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params):
+    """Gradient of pyramid_loss's combined scalar to every flow of the pyramid
+    (core/unsupervised.py:114-141: level i sees flow * final_flow_scale / 2**i and weighs its
+    layer loss by layer_weights[i]).  Returns (grads_fw, grads_bw), None where no loss sees the level."""
+    layer_weights = [12.7, 4.35, 3.9, 3.4, 1.1]
+    layer_patch_distances = [3, 2, 2, 1, 1]
+    if params.get('full_res'):
+        layer_weights = [12.7, 5.5, 5.0, 4.35, 3.9, 3.4, 1.1]
+        layer_patch_distances = [3, 3] + layer_patch_distances
+        im1_s, im2_s, mask_s = _f32(im1_norm), _f32(im2_norm), _f32(border_mask)
+        final_flow_scale = 5.0 * 4
+    else:
+        im1_s, im2_s, mask_s = (util_downsample(t, 4) for t in (im1_norm, im2_norm, border_mask))
+        final_flow_scale = 5.0
+    weights = {k: params[k + '_weight'] for k in LOSSES if params.get(k + '_weight')}
+    n_levels = len(flows_fw) if params.get('pyramid_loss') else 1
+    gfw, gbw = [None] * len(flows_fw), [None] * len(flows_bw)
+    for i in range(n_levels):
+        flow_scale = np.float32(final_flow_scale / (2 ** i))
+        d_fw, d_bw, _ = compute_losses_grad(im1_s, im2_s, _f32(flows_fw[i]) * flow_scale, _f32(flows_bw[i]) * flow_scale,
+                                            mask_s if params.get('border_mask') else None,
+                                            params.get('mask_occlusion', ''), layer_patch_distances[i], weights)
+        gfw[i] = (np.float32(layer_weights[i]) * flow_scale * d_fw).astype(np.float32)
+        gbw[i] = (np.float32(layer_weights[i]) * flow_scale * d_bw).astype(np.float32)
+        if i + 1 < n_levels:
+            im1_s, im2_s, mask_s = (util_downsample(t, 2) for t in (im1_s, im2_s, mask_s))
+    return gfw, gbw
+
+
 # --------------------------------------------------------------------------- integer census (extension)
 def census_transform(im, max_distance=3, eps=0.9):
     """[B,H,W,2] uint64 ternary census signature (definition: include/unflow_hip.h)."""

@@ -589,6 +589,69 @@ def test_compute_losses_vs_oracle(oracle_mod, dev, mask_occlusion, use_border):
     close(fbw.grad, want_dbw, 1e-5, 1e-5 * np.abs(want_dbw).max())
 
 
+KITTI_MIX = dict(ternary=1.0, smooth_2nd=3.0, fb=0.2, occ=12.4)       # config_template/config.ini:123,166-174
+
+
+@pytest.mark.parametrize("mask_occlusion,use_border,weights", [
+    ("fb", True, KITTI_MIX),
+    ("fb", True, dict(KITTI_MIX, photo=0.7, grad=0.5, smooth_1st=0.3, sym=0.1)),   # every entry of losses.py:60-85
+    ("", False, dict(KITTI_MIX, photo=0.7, grad=0.5)),
+    ("disocc", True, dict(ternary=1.0, fb=0.2, grad=0.5)),
+])
+@pytest.mark.parametrize("restrict_terms", [False, True])
+def test_compute_losses_full_mix_gradient_vs_oracle(oracle_mod, dev, mask_occlusion, use_border, weights, restrict_terms):
+    """The gradient the trainer differentiates (losses.py:16-87 under the reference's default loss mix):
+    sum_k w_k * losses[k] back to BOTH flows -- ternary / photo / grad through image_warp's flow
+    gradient, fb through _FlowDiff into image_warp's flow gradient AND its image-gradient scatter
+    into the other flow, the stencil terms directly -- against oracle.compute_losses_grad, the
+    composition checked by central differences in tests/test_oracle_gradients.py.
+    restrict_terms: only the weighted entries are evaluated (the census then runs fused with its
+    warp); otherwise all eight, through the materialised warped images."""
+    from unflow_amd import losses
+    rng = np.random.default_rng(77)
+    B, H, W = 2, 40, 56
+    im1, im2, flow_fw = _pair(rng, B, H, W)
+    flow_bw = (-flow_fw + rng.standard_normal(flow_fw.shape) * 0.5).astype(np.float32)
+    border = oracle_mod.create_border_mask((B, H, W)) if use_border else None
+    want_dfw, want_dbw, want = oracle_mod.compute_losses_grad(im1, im2, flow_fw, flow_bw, border, mask_occlusion, 3,
+                                                              weights)
+    ffw, fbw = T(flow_fw, dev).requires_grad_(True), T(flow_bw, dev).requires_grad_(True)
+    got = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw, None if border is None else T(border, dev),
+                                mask_occlusion, 3, terms=set(weights) if restrict_terms else None)
+    total = sum(w * got[k] for k, w in weights.items())
+    np.testing.assert_allclose(float(total.detach()), sum(w * want[k] for k, w in weights.items()), rtol=1e-5)
+    total.backward()
+    # 1e-5 of the gradient's scale (the bar of the single-term tests above)
+    close(ffw.grad, want_dfw, 1e-5, 1e-5 * np.abs(want_dfw).max())
+    close(fbw.grad, want_dbw, 1e-5, 1e-5 * np.abs(want_dbw).max())
+
+
+@pytest.mark.parametrize("full_res", [False, True])
+def test_pyramid_loss_kitti_mix_gradient_vs_oracle(oracle_mod, dev, full_res):
+    """core/unsupervised.py:83-145 with the reference's default KITTI weights (+ grad): the gradient of
+    the combined scalar to EVERY flow of the pyramid, both directions, against the oracle's
+    composition (layer weight x flow scale x compute_losses_grad per level)."""
+    from unflow_amd import unsupervised
+    rng = np.random.default_rng(34)
+    B, H, W = 2, 128, 192
+    im1, im2, _ = _pair(rng, B, H, W)
+    border = oracle_mod.create_border_mask((B, H, W))
+    levels = 7 if full_res else 5
+    h0, w0 = (H, W) if full_res else (H // 4, W // 4)
+    fws = [(rng.standard_normal((B, h0 >> i, w0 >> i, 2)) * 0.3).astype(np.float32) for i in range(levels)]
+    bws = [(-f + rng.standard_normal(f.shape) * 0.05).astype(np.float32) for f in fws]
+    params = dict(full_res=full_res, pyramid_loss=True, mask_occlusion="fb", border_mask=True,
+                  ternary_weight=1.0, smooth_2nd_weight=3.0, fb_weight=0.2, occ_weight=12.4, grad_weight=0.5)
+    want_fw, want_bw = oracle_mod.pyramid_loss_grad(im1, im2, border, fws, bws, params)
+    tf_ = [T(f, dev).requires_grad_(True) for f in fws]
+    tb_ = [T(f, dev).requires_grad_(True) for f in bws]
+    got, _ = unsupervised.pyramid_loss(T(im1, dev), T(im2, dev), T(border, dev), tf_, tb_, params)
+    got.backward()
+    for i in range(levels):
+        for t, w in ((tf_[i], want_fw[i]), (tb_[i], want_bw[i])):
+            close(t.grad, w, 1e-5, 1e-5 * np.abs(w).max())
+
+
 @pytest.mark.parametrize("full_res,pyramid", [(False, True), (True, True), (False, False)])
 def test_pyramid_loss_vs_oracle(oracle_mod, dev, full_res, pyramid):
     """core/unsupervised.py:83-145: layer weights, patch distances, flow scaling and the

@@ -126,3 +126,52 @@ def test_gradient_loss_grad(oracle_mod):
     g = oracle_mod.gradient_loss_grad(a, b, mask)
     num = np_ref.numeric_grad(lambda x: np_ref.gradient_loss(a, x, mask), b, eps=1e-6)
     np.testing.assert_allclose(g, num, rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("mask_occlusion", ["fb", ""])
+def test_compute_losses_grad_composition(oracle_mod, mask_occlusion):
+    """oracle.compute_losses_grad (the composition TF's autodiff makes of losses.py:16-87) against
+    central differences of the float64 restatement of the same weighted sum, the reference's
+    default KITTI mix plus photo and grad (config_template/config.ini:123,166-174).  The 0/1 masks
+    are piecewise constant in the flows (tf.cast of a comparison): held fixed on the numeric side."""
+    rng = np.random.default_rng(40)
+    B, H, W = 1, 9, 10
+    im1 = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+    im2 = rng.uniform(size=(B, H, W, 3)).astype(np.float32)
+    ffw = away_from_integers(rng, (B, H, W, 2), 1.0)
+    fbw = away_from_integers(rng, (B, H, W, 2), 1.0)
+    border = oracle_mod.create_border_mask((B, H, W)) if mask_occlusion else None
+    wts = dict(ternary=1.0, smooth_2nd=3.0, fb=0.2, occ=12.4, photo=0.7, grad=0.5, smooth_1st=0.3, sym=0.1)
+    r = 2
+    d_fw, d_bw, losses = oracle_mod.compute_losses_grad(im1, im2, ffw, fbw, border, mask_occlusion, r, wts)
+    _, aux = oracle_mod.compute_losses(im1, im2, ffw, fbw, border, mask_occlusion, r)
+    mfw, mbw = aux["mask_fw"], aux["mask_bw"]
+    assert 0 < mfw.sum() < mfw.size or not mask_occlusion
+
+    def warped_terms(f_fw, f_bw):
+        f_fw32, f_bw32 = f_fw.astype(np.float32), f_bw.astype(np.float32)
+        i2w, i1w = np_ref.image_warp(im2, f_fw32), np_ref.image_warp(im1, f_bw32)
+        s = wts["ternary"] * (np_ref.ternary_loss(im1, i2w, mfw, r) + np_ref.ternary_loss(im2, i1w, mbw, r))
+        s += wts["photo"] * (np_ref.charbonnier(im1 - i2w, mfw, beta=255) + np_ref.charbonnier(im2 - i1w, mbw, beta=255))
+        s += wts["grad"] * (np_ref.gradient_loss(im1, i2w, mfw) + np_ref.gradient_loss(im2, i1w, mbw))
+        s += wts["fb"] * (np_ref.charbonnier(f_fw + np_ref.image_warp(f_bw, f_fw32), mfw) +
+                          np_ref.charbonnier(f_bw + np_ref.image_warp(f_fw, f_bw32), mbw))
+        return s                       # occ and sym: functions of the masks alone
+
+    def smooth_terms(f_fw, f_bw):
+        return (wts["smooth_1st"] * (np_ref.smoothness_loss(f_fw, 1) + np_ref.smoothness_loss(f_bw, 1)) +
+                wts["smooth_2nd"] * (np_ref.smoothness_loss(f_fw, 2) + np_ref.smoothness_loss(f_bw, 2)))
+
+    # two step sizes: the warp casts the flow to float32 (1e-3, as test_image_warp_grads); the
+    # charbonnier of a flow difference bends at |delta| ~ epsilon = 1e-3 (1e-6, as test_smoothness_grad)
+    f64 = np.float64
+    n_fw = (np_ref.numeric_grad(lambda x: warped_terms(x, fbw.astype(f64)), ffw, 1e-3) +
+            np_ref.numeric_grad(lambda x: smooth_terms(x, fbw.astype(f64)), ffw, 1e-6))
+    n_bw = (np_ref.numeric_grad(lambda x: warped_terms(ffw.astype(f64), x), fbw, 1e-3) +
+            np_ref.numeric_grad(lambda x: smooth_terms(ffw.astype(f64), x), fbw, 1e-6))
+    # float32 flow perturbation inside the warp: the reference's gradient-check tolerance scaled
+    # to the gradient's size (test/ops/backward_warp.py:21-25 uses 1e-3 on O(1) gradients)
+    for got, num in ((d_fw, n_fw), (d_bw, n_bw)):
+        np.testing.assert_allclose(got, num, rtol=5e-3, atol=5e-3 * np.abs(num).max())
+    # the forward scalars it returns are compute_losses' own
+    assert set(losses) == {"sym", "occ", "photo", "grad", "smooth_1st", "smooth_2nd", "fb", "ternary"}
