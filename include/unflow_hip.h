@@ -233,22 +233,36 @@ int unflow_correlation_flip(const float *in, const float *add, float *out, int B
                             int kernel_size, int max_displacement, int pad, int stride_1,
                             int stride_2, unflow_stream_t stream);
 
-/* ---------------------------------------------------------------- fp16 storage (extension)
+/* ---------------------------------------------------------------- fp16 correlation (extension)
  * NOT in the reference (float32 only; BASELINE config 5 names "fp16 with fp32 accumulate").
- * Correlation with half-precision tensors in HBM: in0, in1 [B,C,H,W] and out
- * [B,441,H,W] are IEEE binary16; they are widened to f32 on the way into LDS, multiplied
- * and accumulated in f32 (every product exact) and rounded to half once on output.
+ * Correlation of half-precision tensors on the f16 MATRIX CORES: in0, in1 [B,C,H,W] and out
+ * [B,441,H,W] are IEEE binary16; v_mfma_f32_16x16x16_f16 multiplies halves (every product exact in
+ * f32) and accumulates in f32; the result is scaled by 1/C and rounded to half once.  Against an
+ * fp32 evaluation of the same half-rounded inputs only the f32 summation order and that one
+ * rounding differ (rtol 2e-3).  Replaces, for half tensors, the same reference
+ * functions as unflow_correlation_fwd / _bwd (ops/correlation_op.cu.cc:250-315, :317-390).
  * FlowNetC attributes only (kernel_size 1, max_displacement = pad = 20, stride_1 1,
  * stride_2 2), W % 4 == 0, 8-byte aligned tensors; otherwise UNFLOW_ERR_INVALID_ARGUMENT. */
 int unflow_correlation_fwd_f16(const void *in0, const void *in1, void *out, int B, int C, int H, int W,
                                int kernel_size, int max_displacement, int pad, int stride_1,
                                int stride_2, unflow_stream_t stream);
-/* Its gradients: topdiff [B,441,H,W], in0, in1, g0, g1 [B,C,H,W], all binary16; f32
- * products and sums, one rounding to half per output element. */
+/* Its gradients: topdiff [B,441,H,W], in0, in1, g0, g1 [B,C,H,W], all binary16; f16 MFMA with
+ * f32 accumulation, one rounding to half per output element. */
 int unflow_correlation_bwd_f16(const void *topdiff, const void *in0, const void *in1, void *g0,
                                void *g1, int B, int C, int H, int W, int kernel_size,
                                int max_displacement, int pad, int stride_1, int stride_2,
                                unflow_stream_t stream);
+/* The same two operations with fp16 STORAGE only: the halves are widened to f32 on the way into
+ * LDS and run through the float32 kernels' f32 MFMA loop, i.e. the k-ordered f32 fmaf chain of
+ * unflow_correlation_fwd on the widened tensors, rounded to half once (bit-identical to that, up to
+ * results on a rounding boundary).  Slower than the float32 op; kept as the exact form. */
+int unflow_correlation_fwd_f16_exact(const void *in0, const void *in1, void *out, int B, int C, int H,
+                                     int W, int kernel_size, int max_displacement, int pad,
+                                     int stride_1, int stride_2, unflow_stream_t stream);
+int unflow_correlation_bwd_f16_exact(const void *topdiff, const void *in0, const void *in1, void *g0,
+                                     void *g1, int B, int C, int H, int W, int kernel_size,
+                                     int max_displacement, int pad, int stride_1, int stride_2,
+                                     unflow_stream_t stream);
 
 /* The warps with fp16 storage (extension, BASELINE config 5: "forward_warp + full-resolution
  * image_warp, fp16 with fp32 accumulate").  Same layouts and semantics as unflow_backward_warp_*,

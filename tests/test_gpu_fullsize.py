@@ -183,11 +183,20 @@ def test_cfg5_shapes_fp32(dev):
         assert abs(float(lhs) - float(rhs)) <= 1e-6 * scale, (float(lhs), float(rhs), scale)
     # fp16 storage at the same shape: equals the f32 kernel on the widened inputs up to the final rounding
     h0, h1 = f0.half(), f1.half()
-    ch = ops.correlation_fp16(h0, h1)
     ref = ops.correlation(h0.float(), h1.float()).half()
+    ch = ops.correlation_fp16_exact(h0, h1)
     assert (ch == ref).float().mean() > 0.99
     torch.testing.assert_close(ch.float(), ref.float(), rtol=2e-3, atol=1e-6)
-    del c, top, g0, g1, df, f0, f1, h0, h1, ch, ref
+    # the f16 matrix-core form: same products, f32 sums in another order (rtol 2e-3), forward and
+    # both gradients against the float32 kernels on the widened tensors
+    ch = ops.correlation_fp16(h0, h1)
+    torch.testing.assert_close(ch.float(), ref.float(), rtol=2e-3, atol=1e-6)
+    th = top.half()
+    gh0, gh1 = ops.correlation_fp16_grad(th, h0, h1)
+    r0, r1 = ops.correlation_grad(th.float(), h0.float(), h1.float())
+    for gg, rr in ((gh0, r0), (gh1, r1)):
+        torch.testing.assert_close(gg.float(), rr.half().float(), rtol=2e-3, atol=2e-4 * float(rr.abs().max()))
+    del c, top, g0, g1, df, f0, f1, h0, h1, ch, ref, th, gh0, gh1, r0, r1
     flow = torch.zeros((16, 768, 1280, 2), device=dev)
     out = ops.forward_warp(flow)
     np.testing.assert_allclose(float(out[:, 10:-10, 10:-10].min()), 6.2831479, rtol=1e-6)

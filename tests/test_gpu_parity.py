@@ -163,10 +163,13 @@ def test_seeded_extensions(seeded, dev):
     np.testing.assert_array_equal(N(dist), seeded["census_dist"])
     assert int(total) == int(seeded["census_total"])
     close(flownet.stacked_inputs(im1, T(seeded["im2"], dev), T(seeded["stacked_flow_lr"], dev)), seeded["stacked_inputs"])
-    got = ops.correlation_fp16(torch.from_numpy(seeded["corr16_f0"]).to(dev), torch.from_numpy(seeded["corr16_f1"]).to(dev))
-    g, w = got.cpu().numpy(), seeded["corr16_out"]
-    np.testing.assert_allclose(g.astype(np.float32), w.astype(np.float32), rtol=2e-3, atol=1e-6)
-    assert (g == w).mean() > 0.99
+    h0, h1 = torch.from_numpy(seeded["corr16_f0"]).to(dev), torch.from_numpy(seeded["corr16_f1"]).to(dev)
+    w = seeded["corr16_out"]
+    for fn, identical in ((ops.correlation_fp16, False), (ops.correlation_fp16_exact, True)):
+        g = fn(h0, h1).cpu().numpy()
+        np.testing.assert_allclose(g.astype(np.float32), w.astype(np.float32), rtol=2e-3, atol=1e-6)
+        if identical:       # f32 MFMA on the widened halves: the oracle's products, rounded once
+            assert (g == w).mean() > 0.99
 
 
 # ----------------------------------------------------------------------------- fresh inputs vs oracle
@@ -223,42 +226,74 @@ def test_correlation_adversarial_cancellation(oracle_mod, dev):
     assert np.abs(got - want).max() <= 1e-5 * scale
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 16, 24), (1, 256, 16, 16), (1, 7, 12, 20), (2, 20, 50, 36)])
-def test_correlation_fp16_storage(oracle_mod, dev, shape):
-    """Extension (BASELINE config 5 wording "fp16 with fp32 accumulate"; not in the reference):
-    half tensors in HBM, f32 products and sums.  Against the fp32 oracle on the SAME
-    half-rounded inputs the only differences are the f32 summation order and the one
-    rounding of the result to half: within one half-ulp (SURVEY 8d asks for rtol 2e-3)."""
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("shape", [(2, 32, 16, 24), (1, 256, 16, 16), (1, 7, 12, 20), (2, 20, 50, 36), (1, 136, 70, 44),
+                                   (1, 16, 2, 4), (1, 3, 33, 8)])
+def test_correlation_fp16(oracle_mod, dev, shape, exact):
+    """Extension (BASELINE config 5 wording "fp16 with fp32 accumulate"; not in the reference): half
+    tensors in HBM, exact f32 products, f32 sums.  ``correlation_fp16`` runs v_mfma_f32_16x16x16_f16,
+    ``correlation_fp16_exact`` widens the halves and runs the float32 op's f32 MFMA loop.  Against the
+    fp32 oracle on the SAME half-rounded inputs the only differences are the f32 summation order and
+    the one rounding of the result to half: SURVEY 8d's rtol 2e-3; the exact form is in addition
+    bit-identical to the rounded oracle except on rounding boundaries.
+    Shapes: several row blocks / column strips / channel groups with tails, odd class extents."""
     from unflow_amd import ops
+    fwd = ops.correlation_fp16_exact if exact else ops.correlation_fp16
     rng = np.random.default_rng(sum(shape))
     f0 = rng.standard_normal(shape).astype(np.float16)
     f1 = rng.standard_normal(shape).astype(np.float16)
     want32, _, _ = oracle_mod.correlation(f0.astype(np.float32), f1.astype(np.float32))
     want = want32.astype(np.float16)
-    got = ops.correlation_fp16(torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev))
+    got = fwd(torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev))
     assert got.dtype == torch.float16 and tuple(got.shape) == want.shape
     g = got.cpu().numpy()
     np.testing.assert_allclose(g.astype(np.float32), want.astype(np.float32), rtol=2e-3, atol=1e-6)
-    assert (g == want).mean() > 0.99            # all but the results that sit on a rounding boundary are identical
-    # and against the fp32 kernel on the widened inputs, rounded the same way
-    ref = ops.correlation(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1.astype(np.float32)).to(dev))
-    assert (got == ref.half()).float().mean() > 0.99
+    # measured: the matrix-core form also lands on the oracle's half almost everywhere (f32 sums of
+    # exact products in another order); only the exact form is REQUIRED to
+    assert (g == want).mean() > (0.99 if exact else 0.97)
+    if exact:   # and against the fp32 kernel on the widened inputs, rounded the same way
+        ref = ops.correlation(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1.astype(np.float32)).to(dev))
+        assert (got == ref.half()).float().mean() > 0.99
     # gradients: oracle on the half-rounded top / inputs, rounded to half
     top = rng.standard_normal(want.shape).astype(np.float16)
     _, p0, p1 = oracle_mod.correlation(f0.astype(np.float32), f1.astype(np.float32))
     w0, w1 = oracle_mod.correlation_grad(top.astype(np.float32), f0.astype(np.float32), f1.astype(np.float32), p0, p1)
     a = torch.from_numpy(f0).to(dev).requires_grad_(True)
     b = torch.from_numpy(f1).to(dev).requires_grad_(True)
-    ops.correlation_fp16(a, b).backward(torch.from_numpy(top).to(dev))
+    fwd(a, b).backward(torch.from_numpy(top).to(dev))
     for gg, ww in ((a.grad, w0), (b.grad, w1)):
         assert gg.dtype == torch.float16
         gnp, wh = gg.cpu().numpy(), ww.astype(np.float16)
         np.testing.assert_allclose(gnp.astype(np.float32), wh.astype(np.float32), rtol=2e-3, atol=2e-4 * np.abs(ww).max())
-        assert (gnp == wh).mean() > 0.98
+        assert (gnp == wh).mean() > (0.98 if exact else 0.95)
     with pytest.raises(ValueError, match="FlowNetC"):
-        ops.correlation_fp16(torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev), max_displacement=4, pad=4)
+        fwd(torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev), max_displacement=4, pad=4)
     with pytest.raises(TypeError):
-        ops.correlation_fp16(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1).to(dev))
+        fwd(torch.from_numpy(f0.astype(np.float32)).to(dev), torch.from_numpy(f1).to(dev))
+
+
+def test_correlation_fp16_known_answers(dev):
+    """Structure of the f16 matrix-core kernels on integer data, where every sum is exact: a one-hot
+    feature map shifted by a displacement puts 1/C on exactly that displacement plane, and the
+    gradients of a one-hot upstream gradient are the other input shifted back."""
+    from unflow_amd import ops
+    B, C, H, W = 1, 16, 40, 48
+    f0 = torch.zeros((B, C, H, W), device=dev, dtype=torch.float16)
+    f1 = torch.zeros_like(f0)
+    f0[0, 3, 17, 22] = 2.0
+    f1[0, 3, 17 + 2 * 4, 22 - 2 * 7] = 3.0          # displacement (dy', dx') = (10 + 4, 10 - 7)
+    out = ops.correlation_fp16(f0, f1)
+    want = torch.zeros_like(out)
+    want[0, (10 + 4) * 21 + (10 - 7), 17, 22] = 6.0 / C
+    assert torch.equal(out, want)
+    top = torch.zeros_like(out)
+    top[0, (10 - 2) * 21 + (10 + 5), 20, 30] = 4.0  # d = (-2, +5) at position (20, 30)
+    a, b = torch.rand_like(f0).round_().requires_grad_(True), torch.rand_like(f0).mul_(4).round_().requires_grad_(True)
+    ops.correlation_fp16(a, b).backward(top)
+    g0, g1 = torch.zeros_like(f0), torch.zeros_like(f0)
+    g0[0, :, 20, 30] = 4.0 / C * b.detach()[0, :, 20 - 4, 30 + 10]
+    g1[0, :, 20 - 4, 30 + 10] = 4.0 / C * a.detach()[0, :, 20, 30]
+    assert torch.equal(a.grad, g0) and torch.equal(b.grad, g1)
 
 
 @pytest.mark.parametrize("B,H,W,C", [(2, 37, 70, 3), (3, 5, 7, 3), (1, 16, 64, 2), (3, 9, 11, 1)])

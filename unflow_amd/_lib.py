@@ -59,6 +59,8 @@ SIGNATURES = {
     "unflow_correlation_flip": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_fwd_f16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_correlation_bwd_f16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "unflow_correlation_fwd_f16_exact": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "unflow_correlation_bwd_f16_exact": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "unflow_backward_warp_fwd_f16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "unflow_backward_warp_bwd_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "unflow_image_warp_fwd_f16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

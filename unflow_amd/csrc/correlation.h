@@ -20,12 +20,16 @@ bool corr_mfma_supported(const CorrGeometry &g, int C);
 bool corr_mfma_bwd_supported(const CorrGeometry &g, int C);
 int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, const CorrGeometry &g,
                   hipStream_t s);
-// fp16 storage, f32 accumulation (extension): half in, half out
+// fp16 storage, f32 MFMA (extension): half in, half out, every product and the k-ordered f32 sum exact
 int corr_mfma_fwd_f16(const void *in0, const void *in1, void *out, int B, int C, const CorrGeometry &g,
                       hipStream_t s);
 int corr_mfma_bwd_f16(const void *topdiff, const void *in0, const void *in1, void *g0, void *g1, int B, int C,
                       const CorrGeometry &g, hipStream_t s);
 int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,
                   const CorrGeometry &g, hipStream_t s);
+// f16 matrix cores (correlation_f16.hip): half in, half out, v_mfma_f32_16x16x16_f16 (f32 accumulate)
+int corr16_fwd(const void *in0, const void *in1, void *out, int B, int C, const CorrGeometry &g, hipStream_t s);
+int corr16_bwd(const void *topdiff, const void *in0, const void *in1, void *g0, void *g1, int B, int C,
+               const CorrGeometry &g, hipStream_t s);
 
 }  // namespace unflow

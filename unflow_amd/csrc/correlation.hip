@@ -228,33 +228,59 @@ extern "C" int unflow_correlation_fwd(const float *in0, const float *in1, float 
   return launch_status("correlation_fwd");
 }
 
+namespace {
+// shared argument checks of the four fp16 entry points; returns UNFLOW_OK with *skip set for empty tensors
+int f16_entry(CorrGeometry *g, int B, int C, int H, int W, int kernel_size, int max_displacement, int pad, int stride_1,
+              int stride_2, bool backward, bool *skip) {
+  if (int rc = corr_geometry_init(g, H, W, kernel_size, max_displacement, pad, stride_1, stride_2)) return rc;
+  const char *what = backward ? "correlation_grad" : "correlation";
+  if (B < 0 || C < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "%s: negative dimension", what);
+  *skip = backward ? (long long)B * C * H * W == 0 : B == 0;
+  if (*skip) return UNFLOW_OK;
+  if (C == 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation: inputs must have at least one channel");
+  if (!(backward ? corr_mfma_bwd_supported(*g, C) : corr_mfma_supported(*g, C)))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT,
+                "%s (fp16) is implemented for the FlowNetC attributes only "
+                "(kernel_size 1, max_displacement 20, pad 20, stride_1 1, stride_2 2)", what);
+  return UNFLOW_OK;
+}
+}  // namespace
+
 extern "C" int unflow_correlation_fwd_f16(const void *in0, const void *in1, void *out, int B, int C, int H, int W,
                                           int kernel_size, int max_displacement, int pad, int stride_1,
                                           int stride_2, unflow_stream_t stream) {
   CorrGeometry g;
-  if (int rc = corr_geometry_init(&g, H, W, kernel_size, max_displacement, pad, stride_1, stride_2)) return rc;
-  if (B < 0 || C < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation: negative dimension");
-  if (B == 0) return UNFLOW_OK;
-  if (C == 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation: inputs must have at least one channel");
-  if (!corr_mfma_supported(g, C))
-    return fail(UNFLOW_ERR_INVALID_ARGUMENT,
-                "correlation (fp16 storage) is implemented for the FlowNetC attributes only "
-                "(kernel_size 1, max_displacement 20, pad 20, stride_1 1, stride_2 2)");
-  return corr_mfma_fwd_f16(in0, in1, out, B, C, g, as_stream(stream));
+  bool skip = false;
+  if (int rc = f16_entry(&g, B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, false, &skip)) return rc;
+  return skip ? UNFLOW_OK : corr16_fwd(in0, in1, out, B, C, g, as_stream(stream));
 }
 
 extern "C" int unflow_correlation_bwd_f16(const void *topdiff, const void *in0, const void *in1, void *g0, void *g1,
                                           int B, int C, int H, int W, int kernel_size, int max_displacement,
                                           int pad, int stride_1, int stride_2, unflow_stream_t stream) {
   CorrGeometry g;
-  if (int rc = corr_geometry_init(&g, H, W, kernel_size, max_displacement, pad, stride_1, stride_2)) return rc;
-  if (B < 0 || C < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "correlation_grad: negative dimension");
-  if ((long long)B * C * H * W == 0) return UNFLOW_OK;
-  if (!corr_mfma_bwd_supported(g, C))
-    return fail(UNFLOW_ERR_INVALID_ARGUMENT,
-                "correlation_grad (fp16 storage) is implemented for the FlowNetC attributes only "
-                "(kernel_size 1, max_displacement 20, pad 20, stride_1 1, stride_2 2)");
-  return corr_mfma_bwd_f16(topdiff, in0, in1, g0, g1, B, C, g, as_stream(stream));
+  bool skip = false;
+  if (int rc = f16_entry(&g, B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, true, &skip)) return rc;
+  return skip ? UNFLOW_OK : corr16_bwd(topdiff, in0, in1, g0, g1, B, C, g, as_stream(stream));
+}
+
+extern "C" int unflow_correlation_fwd_f16_exact(const void *in0, const void *in1, void *out, int B, int C, int H, int W,
+                                                int kernel_size, int max_displacement, int pad, int stride_1,
+                                                int stride_2, unflow_stream_t stream) {
+  CorrGeometry g;
+  bool skip = false;
+  if (int rc = f16_entry(&g, B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, false, &skip)) return rc;
+  return skip ? UNFLOW_OK : corr_mfma_fwd_f16(in0, in1, out, B, C, g, as_stream(stream));
+}
+
+extern "C" int unflow_correlation_bwd_f16_exact(const void *topdiff, const void *in0, const void *in1, void *g0,
+                                                void *g1, int B, int C, int H, int W, int kernel_size,
+                                                int max_displacement, int pad, int stride_1, int stride_2,
+                                                unflow_stream_t stream) {
+  CorrGeometry g;
+  bool skip = false;
+  if (int rc = f16_entry(&g, B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, true, &skip)) return rc;
+  return skip ? UNFLOW_OK : corr_mfma_bwd_f16(topdiff, in0, in1, g0, g1, B, C, g, as_stream(stream));
 }
 
 extern "C" int unflow_correlation_bwd(const float *topdiff, const float *in0, const float *in1,

@@ -278,7 +278,7 @@ def _hp(t):
 
 class _CorrelationFP16(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, first, second, attrs):
+    def forward(ctx, first, second, attrs, exact):
         first, second = _half(first, "first"), _half(second, "second")
         _require_rank4(first, "first")
         if first.shape != second.shape:
@@ -286,23 +286,24 @@ class _CorrelationFP16(torch.autograd.Function):
         B, C, H, W = first.shape
         shapes = correlation_output_shape(first.shape, *attrs)
         out = torch.empty(shapes["correlation"], device=first.device, dtype=torch.float16)
+        lib = _lib.load()
+        fn = lib.unflow_correlation_fwd_f16_exact if exact else lib.unflow_correlation_fwd_f16
         with torch.cuda.device(first.device):
-            _lib.check(_lib.load().unflow_correlation_fwd_f16(_hp(first), _hp(second), _hp(out), B, C, H, W,
-                                                              *attrs, _stream()))
+            _lib.check(fn(_hp(first), _hp(second), _hp(out), B, C, H, W, *attrs, _stream()))
         ctx.save_for_backward(first, second)
-        ctx.attrs = attrs
+        ctx.attrs, ctx.exact = attrs, exact
         return out
 
     @staticmethod
     def backward(ctx, in_grad):
         first, second = ctx.saved_tensors
-        g0, g1 = correlation_fp16_grad(in_grad, first, second, *ctx.attrs)
-        return g0, g1, None
+        g0, g1 = correlation_fp16_grad(in_grad, first, second, *ctx.attrs, exact=ctx.exact)
+        return g0, g1, None, None
 
 
 def correlation_fp16_grad(in_grad, original_input_0, original_input_1, kernel_size=1, max_displacement=20,
-                          pad=20, stride_1=1, stride_2=2):
-    """Gradients of ``correlation_fp16``: all tensors float16, f32 products and sums."""
+                          pad=20, stride_1=1, stride_2=2, exact=False):
+    """Gradients of ``correlation_fp16``: all tensors float16, f32 sums (``exact``: of ``correlation_fp16_exact``)."""
     in_grad = _half(in_grad, "input_grad")
     in0, in1 = _half(original_input_0, "original_input_0"), _half(original_input_1, "original_input_1")
     B, C, H, W = in0.shape
@@ -311,17 +312,26 @@ def correlation_fp16_grad(in_grad, original_input_0, original_input_1, kernel_si
     if tuple(in_grad.shape) != shapes["correlation"]:
         raise ValueError("input_grad has shape %s, expected %s" % (tuple(in_grad.shape), shapes["correlation"]))
     g0, g1 = torch.empty_like(in0), torch.empty_like(in0)
+    lib = _lib.load()
+    fn = lib.unflow_correlation_bwd_f16_exact if exact else lib.unflow_correlation_bwd_f16
     with torch.cuda.device(in0.device):
-        _lib.check(_lib.load().unflow_correlation_bwd_f16(_hp(in_grad), _hp(in0), _hp(in1), _hp(g0), _hp(g1),
-                                                          B, C, H, W, *attrs, _stream()))
+        _lib.check(fn(_hp(in_grad), _hp(in0), _hp(in1), _hp(g0), _hp(g1), B, C, H, W, *attrs, _stream()))
     return g0, g1
 
 
 def correlation_fp16(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
-    """Extension (not in the reference, whose ops are float32 only): ``correlation`` on
-    half-precision tensors -- fp16 in HBM, f32 products and accumulation, one rounding to
-    half on output; differentiable.  FlowNetC attributes only."""
-    return _CorrelationFP16.apply(first, second, (kernel_size, max_displacement, pad, stride_1, stride_2))
+    """Extension (not in the reference, whose ops are float32 only; BASELINE config 5): ``correlation`` on
+    half-precision tensors on the f16 matrix cores -- halves in HBM, exact f32 products, f32
+    accumulation inside ``v_mfma_f32_16x16x16_f16``, one rounding to half on output; differentiable.
+    FlowNetC attributes only."""
+    return _CorrelationFP16.apply(first, second, (kernel_size, max_displacement, pad, stride_1, stride_2), False)
+
+
+def correlation_fp16_exact(first, second, kernel_size=1, max_displacement=20, pad=20, stride_1=1, stride_2=2):
+    """``correlation_fp16`` with fp16 STORAGE only: the halves are widened and run through the float32
+    op's f32 MFMA loop (its k-ordered fmaf chain on the widened tensors, rounded to half once).
+    Slower than the float32 op; kept as the exact form."""
+    return _CorrelationFP16.apply(first, second, (kernel_size, max_displacement, pad, stride_1, stride_2), True)
 
 
 class _WarpFP16(torch.autograd.Function):
