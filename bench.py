@@ -78,15 +78,41 @@ def free_port():
         return s.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs this process tree may use, counted WITHOUT any HIP / torch.cuda call (the launcher parent must not
+    initialise the runtime before it forks the ranks): the visibility variables if set, else the KFD topology
+    (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with simd_count > 0 is a GPU).  None if neither
+    source is readable -- the children then find out themselves (torch.cuda.set_device fails with a status
+    the launcher propagates)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
+            with open(os.path.join(base, node, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    return n
+
+
 def spawn_ranks(args):
     """Start args.gpus children, one rank each, and return the worst exit status.  The
-    parent never initialises the GPU (no HIP call, no torch.cuda query that would) and never
+    parent never initialises the GPU (no HIP call and no torch import at all) and never
     re-execs: children are fresh interpreters."""
     n = args.gpus
     if not args.dry:
-        import torch
-        have = torch.cuda.device_count()          # does not create a HIP context
-        if have < n and not os.environ.get("UNFLOW_BENCH_SHARE_GPU"):
+        have = visible_gpu_count()
+        if have is not None and have < n and not os.environ.get("UNFLOW_BENCH_SHARE_GPU"):
             print("bench.py: --gpus %d but only %d visible" % (n, have), file=sys.stderr)
             return 2
     port = free_port()
@@ -183,14 +209,11 @@ class Workload:
         ls["ternary"].backward()
         return ls
 
-    def step(self, world, bidirectional=False):
+    def step(self, world, bidirectional=False, serialized=False):
         from unflow_amd import dist as udist
         from unflow_amd import ops
         torch = self.torch
-        # N > 1: the gradient buffer's all-reduce runs on RCCL's stream while the step computes (a
-        # bucketed data-parallel trainer overlaps it with the backward pass) and is waited for -- by the
-        # stream, not the host -- before the step ends
-        pending = self.grad_buffer.all_reduce_async() if world > 1 else None
+        order = self.step_order = []
         with torch.no_grad():
             if bidirectional:
                 # extension: corr(b, a) is a bit-exact re-indexing of corr(a, b), and one
@@ -204,12 +227,30 @@ class Workload:
                 c_bw = self._timed("corr_fwd", ops.correlation, self.fb, self.fa)
                 g_fw = self._timed("corr_bwd", ops.correlation_grad, self.top_fw, self.fa, self.fb)
                 g_bw = self._timed("corr_bwd", ops.correlation_grad, self.top_bw, self.fb, self.fa)
+            order += ["corr_fwd", "corr_fwd", "corr_bwd", "corr_bwd"]
+        # N > 1: the gradient buffer stands for the FlowNetC weights' gradient, which a trainer has at the
+        # earliest when the correlation backward is through (core/train.py:446-480 averages after the whole
+        # backward pass).  So its all-reduce is started HERE: an event recorded behind the second
+        # correlation_grad, the collective's stream waits for it, and what is left of the step -- the loss
+        # leg -- is all that can overlap the exchange; the step ends with the launch stream waiting (no
+        # host synchronisation) for the collective.  serialized=True waits at once (no overlap at all).
+        pending = None
+        if world > 1:
+            pending = self.grad_buffer.all_reduce_async(after=udist.record_event())
+            order.append("allreduce_start")
+            if serialized:
+                pending.wait()
+                pending = None
+                order.append("allreduce_wait")
         ls = self.loss_leg()
+        order.append("loss_leg")
         loss = ls["ternary"].detach()
         if world > 1:    # the reference's average_gradients (core/train.py:446-480) as two RCCL all-reduces
             loss = udist.reduce_losses({"ternary": loss})["ternary"]
+            order.append("loss_allreduce")
             if pending is not None:
                 pending.wait()
+                order.append("allreduce_wait")
         return loss, (c_fw, c_bw, g_fw, g_bw)
 
     def composed_loss(self):
@@ -473,6 +514,24 @@ def main():
     bwd_ms = float(np.mean(per_kind["corr_bwd"]))
     fwd_ms = float(np.mean(per_kind["corr_fwd"]))
 
+    # N > 1: the same step with the exchange waited for at once (no overlap) and the bare all-reduce, so that
+    # whatever the scaling run prints is bounded on both sides
+    dt_serial = allreduce_ms = None
+    step_order = list(wl.step_order)
+    if world > 1:
+        fence()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step(world, serialized=True)
+        fence()
+        dt_serial = max_over_ranks(time.perf_counter() - t2)
+        fence()
+        t3 = time.perf_counter()
+        for _ in range(5):
+            wl.grad_buffer.all_reduce()
+        fence()
+        allreduce_ms = max_over_ranks(time.perf_counter() - t3) / 5 * 1e3
+
     dt_bidir = None
     if not args.no_extras:
         # for information only (never `value`): the same step with the bidirectional-correlation extension
@@ -506,8 +565,10 @@ def main():
                                    "[B,256,48,160] + level-0 compute_losses (4 image_warp evaluated inside the census and fb-occlusion "
                                    "kernels, 2 forward_warp + sym term, 2 ternary 7x7) fwd+bwd" % args.batch,
                        "global_batch": args.batch * world, "height": H, "width": W,
-                       "parallelism": "batch-sharded x%d (one process per GPU), all-reduce of loss + 156.7 MB grad buffer (overlapped with the step's compute)" % world,
+                       "parallelism": "batch-sharded x%d (one process per GPU), all-reduce of loss + 156.7 MB grad buffer "
+                                      "(started behind the second correlation_grad, overlapping the loss leg only)" % world,
                        "world_size": world, "backend": dist.get_backend() if world > 1 else None,
+                       **({"step_order": step_order} if world > 1 else {}),
                        **({"rehearsal_all_ranks_on_one_gpu": True} if shared else {})},
             "roofline": {"bound": "mfma",
                          "kernel": "correlation backward: corr_mfma_bwd2_kernel, both gradient launches of one call",
@@ -524,6 +585,10 @@ def main():
                                       "tflops": CORR_FWD_FLOP * args.batch / (fwd_ms * 1e-3) / 1e12,
                                       "frac": CORR_FWD_FLOP * args.batch / (fwd_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TF,
                                       "hbm_gbs": CORR_FWD_BYTES * args.batch / (fwd_ms * 1e-3) / 1e9}},
+            **({"ms_per_step_serialized": dt_serial / args.steps * 1e3, "allreduce_ms": allreduce_ms,
+                "allreduce_note": "ms_per_step: the 156.7 MB all-reduce starts when the correlation backward is through and "
+                                  "overlaps the loss leg; ms_per_step_serialized: the same step waiting for it at once; "
+                                  "allreduce_ms: the bare collective"} if world > 1 else {}),
             "loss": float(loss),
             "loss_check": {"fused": fused, "composed_hip": composed,
                            "note": "rank 0's shard through the fused kernels vs the unfused HIP ops, asserted to 1e-6; "

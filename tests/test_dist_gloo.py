@@ -129,3 +129,27 @@ def test_bench_two_ranks_on_the_gpu_rehearsal():
     assert line["config"]["rehearsal_all_ranks_on_one_gpu"] is True
     assert line["value"] > 0 and abs(line["value"] - 8 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
     assert "cpu_baseline" not in line and line["roofline"]["bound"] == "mfma"
+    # the gradient buffer's all-reduce starts behind the second correlation_grad (the earliest point at which a
+    # trainer has those gradients), overlaps the loss leg only and is waited for at the end of the step
+    order = line["config"]["step_order"]
+    assert order == ["corr_fwd", "corr_fwd", "corr_bwd", "corr_bwd", "allreduce_start", "loss_leg", "loss_allreduce",
+                     "allreduce_wait"], order
+    assert line["ms_per_step_serialized"] > 0 and line["allreduce_ms"] > 0
+
+
+def test_launcher_counts_gpus_without_hip(monkeypatch):
+    """The launcher parent must not initialise HIP before it forks the ranks: it counts the GPUs from the
+    visibility variables or the KFD topology, never through torch.cuda."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2,5")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    assert bench.visible_gpu_count() in (None, 0) or bench.visible_gpu_count() > 0    # KFD topology or unreadable
+    import inspect
+    src = inspect.getsource(bench.spawn_ranks) + inspect.getsource(bench.visible_gpu_count)
+    assert "import torch" not in src and "device_count" not in src

@@ -226,6 +226,16 @@ def test_correlation_adversarial_cancellation(oracle_mod, dev):
     assert np.abs(got - want).max() <= 1e-5 * scale
 
 
+def _between_nans(a, dev):
+    """The array as a tensor in the middle of a larger NaN-filled allocation (8-byte aligned): a kernel that
+    reads outside its tensor -- a channel tail that relies on a range check, a halo row -- shows up as NaN."""
+    t = torch.from_numpy(a)
+    pad = 4096
+    buf = torch.full((t.numel() + 2 * pad,), float("nan"), dtype=t.dtype, device=dev)
+    buf[pad:pad + t.numel()] = t.reshape(-1).to(dev)
+    return buf[pad:pad + t.numel()].view(t.shape)
+
+
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("shape", [(2, 32, 16, 24), (1, 256, 16, 16), (1, 7, 12, 20), (2, 20, 50, 36), (1, 136, 70, 44),
                                    (1, 16, 2, 4), (1, 3, 33, 8)])
@@ -244,7 +254,7 @@ def test_correlation_fp16(oracle_mod, dev, shape, exact):
     f1 = rng.standard_normal(shape).astype(np.float16)
     want32, _, _ = oracle_mod.correlation(f0.astype(np.float32), f1.astype(np.float32))
     want = want32.astype(np.float16)
-    got = fwd(torch.from_numpy(f0).to(dev), torch.from_numpy(f1).to(dev))
+    got = fwd(_between_nans(f0, dev), _between_nans(f1, dev))
     assert got.dtype == torch.float16 and tuple(got.shape) == want.shape
     g = got.cpu().numpy()
     np.testing.assert_allclose(g.astype(np.float32), want.astype(np.float32), rtol=2e-3, atol=1e-6)
@@ -258,9 +268,9 @@ def test_correlation_fp16(oracle_mod, dev, shape, exact):
     top = rng.standard_normal(want.shape).astype(np.float16)
     _, p0, p1 = oracle_mod.correlation(f0.astype(np.float32), f1.astype(np.float32))
     w0, w1 = oracle_mod.correlation_grad(top.astype(np.float32), f0.astype(np.float32), f1.astype(np.float32), p0, p1)
-    a = torch.from_numpy(f0).to(dev).requires_grad_(True)
-    b = torch.from_numpy(f1).to(dev).requires_grad_(True)
-    fwd(a, b).backward(torch.from_numpy(top).to(dev))
+    a = _between_nans(f0, dev).requires_grad_(True)
+    b = _between_nans(f1, dev).requires_grad_(True)
+    fwd(a, b).backward(_between_nans(top, dev))
     for gg, ww in ((a.grad, w0), (b.grad, w1)):
         assert gg.dtype == torch.float16
         gnp, wh = gg.cpu().numpy(), ww.astype(np.float16)

@@ -32,6 +32,9 @@ rows = [("f32 fwd", lambda: ops.correlation(f0, f1)), ("f32 bwd", lambda: ops.co
         ("f16 storage (exact) bwd", lambda: ops.correlation_fp16_grad(th, h0, h1, exact=True)),
         ("f16 matrix cores fwd", lambda: ops.correlation_fp16(h0, h1)),
         ("f16 matrix cores bwd", lambda: ops.correlation_fp16_grad(th, h0, h1))]
+if "--only16" in sys.argv:      # A/B runs of variant builds (UNFLOW_HIP_LIB=unflow_amd/variants/<name>.so)
+    rows = rows[4:]
+    print("build:", os.environ.get("UNFLOW_HIP_LIB", "default"))
 with torch.no_grad():
     for name, fn in rows:
         print("%-28s %8.3f ms" % (name, timeit(fn)), flush=True)

@@ -136,11 +136,13 @@ struct FwdStager16 {
     rs1 = make_rsrc16(in1 + (item * C + c0) * plane, bytes);
   }
   __device__ inline void load() {
-    const int second = (int)(8 * plane * 2);     // channel wave + 8 (beyond the last channel: range check -> 0)
+    // channel wave + 8: in the VECTOR offset -- the range check that zero-fills the channels beyond the last
+    // one looks at the vector offset only, not at the scalar one (OOB + this stays out of range: C*H*W*2 < 2^31)
+    const unsigned second = (unsigned)(8 * plane * 2);
 #pragma unroll
     for (int j = 0; j < F1_ROUNDS; ++j) {
       r1[0][j] = __builtin_amdgcn_raw_buffer_load_b64(rs1, (int)voff1[j], 0, 0);
-      r1[1][j] = __builtin_amdgcn_raw_buffer_load_b64(rs1, (int)voff1[j], voff1[j] == OOB ? 0 : second, 0);
+      r1[1][j] = __builtin_amdgcn_raw_buffer_load_b64(rs1, (int)(voff1[j] + second), 0, 0);
     }
     r0v = __builtin_amdgcn_raw_buffer_load_b64(rs0, (int)voff0, 0, 0);
   }
@@ -337,11 +339,15 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr16_fwd_kernel(const _Float16 
 //
 // Workgroup = (pair, row class, 128 channels, block of 16 class rows x 8 class columns x both column
 // classes); 8 waves = {column class} x {2 column tiles} x {2 pairs of tile rows}, 2 tiles x 8 M-tiles of
-// accumulators per wave.  It walks the 36 window rows of its block in 18 pairs; a stage holds
+// accumulators per wave.  It walks the 36 window rows of its block in 18 pairs.  ONE LDS stage (64 KB, so
+// that two workgroups share a CU and one's staging hides behind the other's MFMAs):
 //   F, per column class: [2 rows][128 channels][28 columns (pitch 40)] halves  (ds_read_b64 of 16 channels x
 //      2 k-groups: 80-byte pitch = 10 slots -> the even slots, the second k-group the odd ones: conflict free),
-//   T, per column class and tile: [12 k-groups][16 positions][4 halves]  (a half-wave reads 32 consecutive
-//      8-byte slots), written value by value (ds_write_b16) from the staged top rows.
+//   T, per column class and tile: [12 k-groups][16 positions][4 halves] (+4: the tile stride shifts the banks
+//      by 2), read as 32 consecutive 8-byte slots per half-wave, written value by value (ds_write_b16).
+// The next pair is loaded into registers while this one computes; a thread's pieces differ only by constants
+// from round to round (F: 32 channels further; T: 4 (wrt 0) or 2 (wrt 1) displacement columns further), so
+// the addresses are one register plus immediates and the lanes of a store instruction spread over the banks.
 // ===========================================================================
 constexpr int BR = 16, BC = 8;                 // block: class rows x class columns (per column class)
 constexpr int BTR = BR / TP, BTC = BC / TP;    // 4 x 2 tiles per column class
@@ -353,23 +359,24 @@ constexpr int FB_PITCH = 40;                   // halves: 80 B
 constexpr int FB_ROW = CWB * FB_PITCH;         // one window row of one class: 5120 halves
 constexpr int FB_CLS = 2 * FB_ROW;             // 10240
 constexpr int KG = 2 * TQ;                     // 12 k-groups (of 4 window columns) per pair of window rows
-constexpr int TB_TILE = KG * 16 * 4;           // 768 halves per tile
-constexpr int TB_CLS = BTR * BTC * TB_TILE;    // 6144
+constexpr int TB_TILE = KG * 16 * 4 + 4;       // 772 halves per tile
+constexpr int TB_CLS = BTR * BTC * TB_TILE;    // 6176
 constexpr int TB_BASE = 2 * FB_CLS;            // [F class 0][F class 1][T class 0][T class 1]
-constexpr int BSTAGE_H = 2 * (FB_CLS + TB_CLS);// 32768 halves = 64 KB
-constexpr int BWD_LDS_BYTES = 2 * BSTAGE_H * 2;// 131072 B
+constexpr int BSTAGE_H = 2 * (FB_CLS + TB_CLS);// 32832 halves
+constexpr int BWD_LDS_BYTES = BSTAGE_H * 2;    // 65664 B: two workgroups per CU
 constexpr int OB_HALVES = CWB * BR * 2 * BC;   // epilogue image [128 channels][16 rows][16 full-res columns] halves = 64 KB
-static_assert(OB_HALVES * 2 <= BWD_LDS_BYTES, "epilogue image must fit the staging buffers");
-static_assert(WROWS % 2 == 0 && (FB_PITCH * 2 / 8) % 2 == 0 && (FB_PITCH * 2 / 8) % 4 == 2, "F image bank pattern");
+static_assert(OB_HALVES * 2 <= BWD_LDS_BYTES, "epilogue image must fit the stage");
+static_assert(WROWS % 2 == 0 && (FB_PITCH * 2 / 8) % 4 == 2 && TB_TILE % 4 == 0 && (TB_TILE / 2) % 32 == 2, "LDS bank patterns");
 
 template <bool WRT1>
-__global__ __launch_bounds__(NTHREADS, 2) void corr16_bwd_kernel(const _Float16 *__restrict__ topdiff,
+__global__ __launch_bounds__(NTHREADS, 4) void corr16_bwd_kernel(const _Float16 *__restrict__ topdiff,
                                                                  const _Float16 *__restrict__ fin,
                                                                  _Float16 *__restrict__ gout, int C, int H, int W,
                                                                  int nbx, int nrb, int nch) {
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = (int)threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   __builtin_assume(wave >= 0 && wave < NWAVES);
   const int cx = wave & 1, tx = (wave >> 1) & 1, th = wave >> 2;
   int vb = xcd_remap(blockIdx.x, gridDim.x);
@@ -388,59 +395,51 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr16_bwd_kernel(const _Float16 
   const long long plane = (long long)H * W;
   const __amdgpu_buffer_rsrc_t rtop = make_rsrc16(topdiff + item * (GW * GW) * plane, (long long)GW * GW * plane * 2);
   const __amdgpu_buffer_rsrc_t rin = make_rsrc16(fin + (item * C + c0) * plane, (long long)(C - c0) * plane * 2);
+  const int dplane2 = (int)(plane * 2);        // bytes per displacement / channel plane
+  const int row_bytes = S * W * 2;             // one class row further down
 
-  // ---- staging pieces (everything that does not depend on the window row is computed once)
-  // F: 2 rows x 128 channels x 14 pieces of 4 full-resolution columns = 3584 pieces, 7 per thread
-  constexpr int F_ROW_PIECES = S * FB_COLS / 4;                  // 14
-  constexpr int F_PER_THREAD = 2 * CWB * F_ROW_PIECES / NTHREADS; // 7
-  static_assert(2 * CWB * F_ROW_PIECES % NTHREADS == 0, "F pieces must split evenly");
-  unsigned f_voff[F_PER_THREAD];   // byte offset at class row 0 (or OOB)
-  int f_lds[F_PER_THREAD];         // half offset inside the class-0 F image (>= FB_ROW: second row of the pair)
-#pragma unroll
-  for (int j = 0; j < F_PER_THREAD; ++j) {
-    const int f = j * NTHREADS + (int)threadIdx.x;
-    const int pc = f % F_ROW_PIECES, c = (f / F_ROW_PIECES) % CWB, r = f / (F_ROW_PIECES * CWB);
-    const int X = S * (xs0 - R) + 4 * pc;
-    f_voff[j] = (X >= 0 && X < W && c0 + c < C) ? (unsigned)((c * plane + (long long)cy * W + X) * 2) : OOB;
-    f_lds[j] = r * FB_ROW + c * FB_PITCH + 2 * pc;
+  // ---- F pieces: round j = (row r = j / 4 of the pair, channels 32 (j % 4) + tid / 16), piece tid % 16 (< 14) of
+  // 4 full-resolution columns
+  constexpr int F_ROUNDS = 8;
+  const int fpc = tid & 15, fcl = tid >> 4;
+  const int fX = S * (xs0 - R) + 4 * fpc;
+  const unsigned f_v0 = (fpc < S * FB_COLS / 4 && fX >= 0 && fX < W) ? (unsigned)((fcl * plane + (long long)cy * W + fX) * 2) : OOB;
+  const int f_l0 = fcl * FB_PITCH + 2 * fpc;
+
+  // ---- T pieces.  A thread owns ONE (block row oyl, row r of the pair, column piece) and walks the displacement
+  // columns ex' = e0 + ESTEP j; per pair only ey' = w - oy + R changes.
+  //   wrt 0: top[(ey', ex'), row oy, 4 halves = positions (ox, ox + 1) of both classes];  ESTEP 4, 6 rounds
+  //   wrt 1: top[(2R - ey', 2R - ex'), row w, 2 halves = position ox + ex' - R of both classes] (a 4-half piece
+  //          could straddle the image edge);  ESTEP 2, 11 rounds
+  // Lane bits are chosen so that the 32 lanes of a store instruction hit 32 different banks (wrt 0) / 16 (wrt 1).
+  constexpr int ESTEP = WRT1 ? 2 : 4, T_ROUNDS = WRT1 ? 11 : 6;
+  int oyl, tr, oxl, e0;
+  if (WRT1) {
+    oxl = (tid & 3) + 4 * ((tid >> 4) & 1);
+    oyl = ((tid >> 2) & 3) + 4 * (tid >> 7);
+    e0 = (tid >> 5) & 1;
+    tr = (tid >> 6) & 1;
+  } else {
+    oxl = 2 * (tid & 1) + 4 * ((tid >> 1) & 1);
+    oyl = ((tid >> 2) & 3) + 4 * (tid >> 7);
+    e0 = 2 * ((tid >> 4) & 1) + ((tid >> 5) & 1);
+    tr = (tid >> 6) & 1;
   }
-  // T: per pair of window rows, for each of the 16 block rows oy and both rows r of the pair, the 21
-  // displacement columns ex' of the row segment of top that holds T(o, (w - oy, ex' - R)): pieces of NPH halves.
-  //   wrt 0: top[(ey', ex'), row oy, columns of the block]: 4 halves = positions (ox, ox + 1) of both
-  //          classes, 16 x 2 x 21 x 4 = 2688 pieces
-  //   wrt 1: top[(2R - ey', 2R - ex'), row w, columns shifted by ex' - R]: a 4-half piece could straddle the
-  //          image edge, so 2 halves = one position of both classes, 5376 pieces
-  // The byte offset of a piece is  t_base + ey'-term + row-term  with only the last two depending on the pair.
-  constexpr int NPH = WRT1 ? 2 : 4;
-  constexpr int T_ROW_PIECES = S * BC / NPH;                      // 4 or 8 pieces per 16 full-res columns
-  constexpr int T_PIECES = BR * 2 * GW * T_ROW_PIECES;
-  constexpr int T_PER_THREAD = (T_PIECES + NTHREADS - 1) / NTHREADS;   // 6 or 11 (last round partial)
-  int t_base[T_PER_THREAD];        // byte offset of the piece without the pair-dependent terms
-  int t_meta[T_PER_THREAD];        // oyl | r << 8, or -1: the piece lies outside the image for every pair
-  int t_lds[T_PER_THREAD];         // half offset of (first position of the piece, its k) inside the class-0 T image
-  int t_lds2[WRT1 ? 1 : T_PER_THREAD];   // wrt 0: the same for the piece's second position (k one further)
-  const int dplane2 = (int)(plane * 2);                            // bytes per displacement plane
-  auto t_slot = [](int oyl, int oxl, int r, int exp_) {
-    // position (oyl, oxl) of the block: tile (oyl / 4, oxl / 4), n = 4 (oyl % 4) + oxl % 4; k = ex' + oxl % 4 + 24 r
-    const int k = exp_ + (oxl & 3) + WIN * r;
-    return ((oyl >> 2) * BTC + (oxl >> 2)) * TB_TILE + ((k >> 2) * 16 + 4 * (oyl & 3) + (oxl & 3)) * 4 + (k & 3);
+  const int tX0 = S * (xs0 + oxl) + (WRT1 ? S * (e0 - R) : 0);     // full-resolution column of round 0 (wrt 1: + 4 j)
+  const bool t_ok = by0 + oyl < hs && (WRT1 || tX0 < W);
+  int t_b0;                                                        // byte offset of round 0 without the pair terms
+  if (WRT1) t_b0 = (2 * R - e0) * dplane2 + (cy * W + tX0) * 2;    // round j: - 2 j planes + 8 j bytes
+  else t_b0 = e0 * dplane2 + ((S * (by0 + oyl) + cy) * W + tX0) * 2;   // round j: + 4 j planes
+  auto t_slot = [&](int k, int ox) {   // (position (oyl, ox), k) inside the class-0 T image
+    return ((oyl >> 2) * BTC + (ox >> 2)) * TB_TILE + ((k >> 2) * 16 + 4 * (oyl & 3) + (ox & 3)) * 4 + (k & 3);
   };
-#pragma unroll
-  for (int j = 0; j < T_PER_THREAD; ++j) {
-    const int f = j * NTHREADS + (int)threadIdx.x;
-    const int pc = f % T_ROW_PIECES, exp_ = (f / T_ROW_PIECES) % GW, r = (f / (T_ROW_PIECES * GW)) & 1;
-    const int oyl = f / (T_ROW_PIECES * GW * 2);
-    const int oxl = pc * (NPH / 2);                              // first class column of the piece inside the block
-    const int X = S * (xs0 + oxl) + (WRT1 ? S * (exp_ - R) : 0); // full-resolution column of the piece in top
-    const bool ok = f < T_PIECES && X >= 0 && X < W && by0 + oyl < hs;
-    t_meta[j] = ok ? (oyl | (r << 8)) : -1;
-    if (WRT1) t_base[j] = (2 * R - exp_) * dplane2 + (cy * W + X) * 2;
-    else t_base[j] = exp_ * dplane2 + ((S * (by0 + oyl) + cy) * W + X) * 2;
-    t_lds[j] = t_slot(oyl & (BR - 1), oxl, r, exp_);
-    if constexpr (!WRT1) t_lds2[j] = t_slot(oyl & (BR - 1), oxl + 1, r, exp_);
-  }
+  const int k0 = e0 + (oxl & 3) + WIN * tr;                         // k of round 0; k = ex' + ox % 4 + 24 r
+  // wrt 0: k = k0 + 4 j -> slot + 64 j;  second position (ox + 1): k + 1
+  // wrt 1: k = k0 + 2 j -> even j: slot(k0) + 64 (j / 2), odd j: slot(k0 + 2) + 64 (j / 2)
+  const int t_s0 = t_slot(k0, oxl);
+  const int t_s1 = WRT1 ? t_slot(k0 + 2, oxl) : t_slot(k0 + 1, oxl + 1);
 
-  // ---- fragment addresses (halves inside a stage)
+  // ---- fragment addresses (halves inside the stage)
   // A: lane = (channel m = lane & 15, k-group g = lane >> 4); MFMA i takes the k-groups 4i + g
   // B: lane = (position n = lane & 15, k-group g)
   const int m = lane & 15, g = lane >> 4;
@@ -460,98 +459,105 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr16_bwd_kernel(const _Float16 
 
   // the k slots no displacement maps to (k < ox % 4 or k > 20 + ox % 4) and the positions outside the image
   // are never written: they stay zero for the whole kernel
-  for (int i = threadIdx.x; i < BSTAGE_H; i += NTHREADS) {         // ints of both stages
-    const int stage = i / (BSTAGE_H / 2), o = i % (BSTAGE_H / 2);
-    if (o >= TB_BASE / 2) reinterpret_cast<int *>(ldsh + stage * BSTAGE_H)[o] = 0;
-  }
-  __syncthreads();
+  for (int i = tid; i < TB_CLS; i += NTHREADS) reinterpret_cast<int *>(ldsh + TB_BASE)[i] = 0;
 
-  i32x2 rf[F_PER_THREAD];
-  std::conditional_t<WRT1, int, i32x2> rt[T_PER_THREAD];
-  const int row_bytes = S * W * 2;             // one class row further down
+  i32x2 rf[F_ROUNDS];
+  std::conditional_t<WRT1, int, i32x2> rt[T_ROUNDS];
   auto load_pair = [&](int pr) {
     const int w0 = by0 - R + 2 * pr;           // first window row (class row) of the pair
 #pragma unroll
-    for (int j = 0; j < F_PER_THREAD; ++j) {
-      const int w = w0 + (f_lds[j] >= FB_ROW ? 1 : 0);
-      const bool ok = w >= 0 && w < hs && f_voff[j] != OOB;
-      const unsigned voff = ok ? f_voff[j] + (unsigned)(w * row_bytes) : OOB;
-      rf[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, (int)voff, 0, 0);
+    for (int j = 0; j < F_ROUNDS; ++j) {
+      const int w = w0 + j / 4;
+      // the channel goes into the VECTOR offset (the range check ignores the scalar one); rows are tested here
+      const bool ok = w >= 0 && w < hs && f_v0 != OOB && c0 + fcl + 32 * (j & 3) < C;
+      rf[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, ok ? (int)(f_v0 + (unsigned)((j & 3) * 32) * (unsigned)dplane2) : (int)OOB,
+                                                   ok ? w * row_bytes : 0, 0);
     }
+    const int w = w0 + tr;
+    const int eyp = w - (by0 + oyl) + R;       // ey' of T(o, e): e_y = w - oy
+    const bool ok = t_ok && eyp >= 0 && eyp <= 2 * R && w >= 0 && w < hs;
+    const int base = t_b0 + (WRT1 ? (2 * R - eyp) * GW * dplane2 + w * row_bytes : eyp * GW * dplane2);
 #pragma unroll
-    for (int j = 0; j < T_PER_THREAD; ++j) {
-      const int oyl = t_meta[j] & 0xff, r = (t_meta[j] >> 8) & 1;
-      const int w = w0 + r;
-      const int eyp = w - (by0 + oyl) + R;                         // ey' of T(o, e): e_y = w - oy
-      const bool ok = t_meta[j] >= 0 && eyp >= 0 && eyp <= 2 * R && w >= 0 && w < hs;
-      int off;
-      if (WRT1) off = t_base[j] + (2 * R - eyp) * GW * dplane2 + w * row_bytes;   // top[d = -e, row w]
-      else off = t_base[j] + eyp * GW * dplane2;                                  // top[d = e, row oy]
-      const unsigned voff = ok ? (unsigned)off : OOB;
-      if constexpr (WRT1) rt[j] = __builtin_amdgcn_raw_buffer_load_b32(rtop, (int)voff, 0, 0);
-      else rt[j] = __builtin_amdgcn_raw_buffer_load_b64(rtop, (int)voff, 0, 0);
+    for (int j = 0; j < T_ROUNDS; ++j) {
+      bool okj = ok && e0 + ESTEP * j <= 2 * R;
+      if constexpr (WRT1) {
+        const int X = tX0 + 4 * j;
+        okj = okj && X >= 0 && X < W;
+        rt[j] = __builtin_amdgcn_raw_buffer_load_b32(rtop, okj ? base - 2 * j * dplane2 + 8 * j : (int)OOB, 0, 0);
+      } else {
+        rt[j] = __builtin_amdgcn_raw_buffer_load_b64(rtop, okj ? base + 4 * j * dplane2 : (int)OOB, 0, 0);
+      }
     }
   };
-  auto store_pair = [&](_Float16 *stage) {
+  auto store_pair = [&]() {
 #pragma unroll
-    for (int j = 0; j < F_PER_THREAD; ++j) {
-      *reinterpret_cast<int *>(stage + f_lds[j]) = class0_of(rf[j]);
-      *reinterpret_cast<int *>(stage + FB_CLS + f_lds[j]) = class1_of(rf[j]);
+    for (int j = 0; j < F_ROUNDS; ++j) {
+      if (fpc < S * FB_COLS / 4) {
+        _Float16 *dst = ldsh + f_l0 + (j / 4) * FB_ROW + (j & 3) * 32 * FB_PITCH;
+        *reinterpret_cast<int *>(dst) = class0_of(rf[j]);
+        *reinterpret_cast<int *>(dst + FB_CLS) = class1_of(rf[j]);
+      }
     }
-    unsigned short *tb = reinterpret_cast<unsigned short *>(stage + TB_BASE);
+    unsigned short *tb = reinterpret_cast<unsigned short *>(ldsh + TB_BASE);
+    if (t_ok) {
 #pragma unroll
-    for (int j = 0; j < T_PER_THREAD; ++j) {
-      if (t_meta[j] >= 0) {
-        if constexpr (WRT1) {
-          const unsigned v = (unsigned)rt[j];                     // (class 0, class 1) of one position
-          tb[t_lds[j]] = (unsigned short)v;
-          tb[TB_CLS + t_lds[j]] = (unsigned short)(v >> 16);
-        } else {
-          const unsigned v0 = (unsigned)rt[j].x, v1 = (unsigned)rt[j].y;   // positions ox, ox + 1 (ox even)
-          tb[t_lds[j]] = (unsigned short)v0;
-          tb[TB_CLS + t_lds[j]] = (unsigned short)(v0 >> 16);
-          tb[t_lds2[j]] = (unsigned short)v1;
-          tb[TB_CLS + t_lds2[j]] = (unsigned short)(v1 >> 16);
+      for (int j = 0; j < T_ROUNDS; ++j) {
+        if (e0 + ESTEP * j <= 2 * R) {
+          if constexpr (WRT1) {
+            const unsigned v = (unsigned)rt[j];                   // (class 0, class 1) of one position
+            const int s = ((j & 1) ? t_s1 : t_s0) + 64 * (j / 2);
+            tb[s] = (unsigned short)v;
+            tb[TB_CLS + s] = (unsigned short)(v >> 16);
+          } else {
+            const unsigned v0 = (unsigned)rt[j].x, v1 = (unsigned)rt[j].y;   // positions ox, ox + 1 (ox even)
+            tb[t_s0 + 64 * j] = (unsigned short)v0;
+            tb[TB_CLS + t_s0 + 64 * j] = (unsigned short)(v0 >> 16);
+            tb[t_s1 + 64 * j] = (unsigned short)v1;
+            tb[TB_CLS + t_s1 + 64 * j] = (unsigned short)(v1 >> 16);
+          }
         }
       }
     }
   };
 
   // pairs of window rows that touch the image: w in [0, hs)
-  const int pr_first = max(0, (R - by0) / 2);                                   // first pair with w0 + 1 >= 0
+  const int pr_first = max(0, (R - by0) / 2);                                   // first pair with w0 >= 0 (w0 is even)
   const int pr_last = min(NPAIRS - 1, (hs - 1 - (by0 - R)) / 2);                // last pair with w0 <= hs - 1
-  // tile row T (0..3) of the block is live for pairs with rows in [4T - R, 4T + 3 + R] (block-relative
-  // window row index wr = w - (by0 - R) in [4T, 4T + 23]): pairs 2T .. 2T + 11
+  // tile row T (0..3) of the block is live for the window rows [4T - R, 4T + 3 + R] relative to by0, i.e. for
+  // the pairs 2T .. 2T + 11
   load_pair(pr_first);
-  store_pair(ldsh + (pr_first & 1) * BSTAGE_H);
+  __syncthreads();                             // the zero fill of the T image is complete
+  store_pair();
   __syncthreads();
   for (int pr = pr_first; pr <= pr_last; ++pr) {
-    const _Float16 *cur = ldsh + (pr & 1) * BSTAGE_H;
-    _Float16 *nxt = ldsh + ((pr + 1) & 1) * BSTAGE_H;
     const bool more = pr < pr_last;
-    if (more) load_pair(pr + 1);
+    if (more) load_pair(pr + 1);               // lands in registers while this pair computes
     const bool live0 = pr >= 2 * (2 * th) && pr <= 2 * (2 * th) + 11;
     const bool live1 = pr >= 2 * (2 * th + 1) && pr <= 2 * (2 * th + 1) + 11;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      f16x4 a[MTB];
+      const f16x4 b0 = *reinterpret_cast<const f16x4 *>(ldsh + b_off[i]);
+      const f16x4 b1 = *reinterpret_cast<const f16x4 *>(ldsh + b_off[i] + BTC * TB_TILE);
 #pragma unroll
-      for (int mt = 0; mt < MTB; ++mt)
-        a[mt] = *reinterpret_cast<const f16x4 *>(cur + a_off[i] + mt * 16 * FB_PITCH);
-      // the T image of a pair is laid out for THAT pair's window rows: the k-groups of tile row T start at
-      // window row index 4T, i.e. pair 2T: group G of the MFMA refers to rows (pr, pr + 1) relative to the tile
-      const f16x4 b0 = *reinterpret_cast<const f16x4 *>(cur + b_off[i]);
-      const f16x4 b1 = *reinterpret_cast<const f16x4 *>(cur + b_off[i] + BTC * TB_TILE);
-      if (live0) {
+      for (int hm = 0; hm < 2; ++hm) {         // M-tiles in two halves: 8 fragment registers instead of 16
+        f16x4 a[MTB / 2];
 #pragma unroll
-        for (int mt = 0; mt < MTB; ++mt) acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], b0, acc[0][mt], 0, 0, 0);
-      }
-      if (live1) {
+        for (int mt = 0; mt < MTB / 2; ++mt)
+          a[mt] = *reinterpret_cast<const f16x4 *>(ldsh + a_off[i] + (hm * (MTB / 2) + mt) * 16 * FB_PITCH);
+        if (live0) {
 #pragma unroll
-        for (int mt = 0; mt < MTB; ++mt) acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], b1, acc[1][mt], 0, 0, 0);
+          for (int mt = 0; mt < MTB / 2; ++mt)
+            acc[0][hm * (MTB / 2) + mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], b0, acc[0][hm * (MTB / 2) + mt], 0, 0, 0);
+        }
+        if (live1) {
+#pragma unroll
+          for (int mt = 0; mt < MTB / 2; ++mt)
+            acc[1][hm * (MTB / 2) + mt] = __builtin_amdgcn_mfma_f32_16x16x16f16(a[mt], b1, acc[1][hm * (MTB / 2) + mt], 0, 0, 0);
+        }
       }
     }
-    if (more) store_pair(nxt);
+    __syncthreads();                           // every wave has read this pair's images
+    if (more) store_pair();
     __syncthreads();
   }
 
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr16_bwd_kernel(const _Float16 
     }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < OB_HALVES / 4; idx += NTHREADS) {
+  for (int idx = tid; idx < OB_HALVES / 4; idx += NTHREADS) {
     const int c4 = idx % (S * BC / 4);
     const int rr = (idx / (S * BC / 4)) % BR;
     const int cl = idx / (S * BC / 4 * BR);

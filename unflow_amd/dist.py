@@ -79,15 +79,47 @@ class FlatGradBuffer:
 
     def __init__(self, numel, device):
         self.buffer = torch.zeros(int(numel), device=device, dtype=torch.float32)
+        self._comm_stream = None
 
     def all_reduce(self):
         all_reduce_sum_(self.buffer)
         return self.buffer
 
-    def all_reduce_async(self):
-        """Starts the SUM all-reduce on the collective's own stream and returns a handle whose ``wait()``
-        makes the current stream wait for it (no host synchronisation) -- the way a bucketed data-parallel
-        trainer overlaps its gradient exchange with the backward pass.  None for a single process."""
-        if dist.is_initialized() and dist.get_world_size() > 1:
+    def all_reduce_async(self, after=None):
+        """Starts the SUM all-reduce and returns a handle whose ``wait()`` makes the CURRENT stream wait for
+        it (no host synchronisation).  ``after``: an event (``record_event()``) the buffer's contents depend
+        on; the collective is issued from a side stream that first waits for it, so nothing enqueued on the
+        launch stream after the event delays the exchange and the exchange cannot start before the event --
+        the way a bucketed data-parallel trainer hands a finished gradient bucket to its communication
+        stream.  None for a single process."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return None
+        if after is None or not self.buffer.is_cuda:
             return dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, async_op=True)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=self.buffer.device)
+        self._comm_stream.wait_event(after)
+        with torch.cuda.stream(self._comm_stream):
+            work = dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, async_op=True)
+        return _StreamWork(work, self._comm_stream)
+
+
+class _StreamWork:
+    """``wait()``: the current stream waits for the collective (and for the side stream it was issued from)."""
+
+    def __init__(self, work, stream):
+        self.work, self.stream = work, stream
+
+    def wait(self):
+        with torch.cuda.stream(self.stream):
+            self.work.wait()                     # the side stream waits for the collective's own stream
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+def record_event():
+    """An event behind everything enqueued so far on the current stream (None without a GPU)."""
+    if not torch.cuda.is_available():
         return None
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
