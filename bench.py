@@ -49,6 +49,7 @@ CORR_BWD_BYTES = 4 * H8 * W8 * (D + 4 * FEAT_C)          # 45.0 MB
 CORR_BWD_FLOP = 2 * CORR_FWD_FLOP                        # 3.47 GFLOP
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MATRIX_PEAK_TF = 157.3  # MI355X_MICROARCH.md: dense f32 MFMA peak
+F16_MATRIX_PEAK_TF = 2516.6  # MI355X_MICROARCH.md: dense f16 / bf16 MFMA peak (16x the f32 matrix rate, "~2.5 PF")
 KITTI = dict(pyramid_loss=True, border_mask=True, mask_occlusion="fb", ternary_weight=1.0,
              smooth_2nd_weight=3.0, fb_weight=0.2, occ_weight=12.4)   # config_template/config.ini:79,98,123,166-174
 
@@ -69,6 +70,10 @@ def parse_args(argv=None):
                     help="process-group backend (default: nccl = RCCL)")
     ap.add_argument("--dry", action="store_true",
                     help="launch and rendezvous only: no GPU work (CPU rehearsal of the N-rank launch path)")
+    ap.add_argument("--config", default="cfg3", choices=("cfg2", "cfg3", "cfg5"),
+                    help="BASELINE.json config: cfg3 (default, the headline: full loss path, batch 32, fp32); cfg2 "
+                         "(batch 8: correlation + bidirectional backward warp, fp32) and cfg5 (768x1280 batch 16, fp16 "
+                         "on the f16 matrix cores) print informational lines, single GPU")
     return ap.parse_args(argv)
 
 
@@ -437,6 +442,112 @@ def traffic_record():
                "(gfx950), per call = both gradient launches; not measured in this run"}
 
 
+# ============================================================================= the other single-GPU configs (informational)
+def run_side_config(args):
+    """BASELINE.json configs[1] (cfg2) and configs[4] (cfg5) as bench lines of their own: same contract, single
+    GPU, never the headline.  cfg2 = SURVEY 8d: B=8, 2 FlowNetC correlation calls (fw and bw direction) on
+    [8,256,48,160] + bidirectional backward_warp (2 calls on [8,384,1280,3]); image_warp (what the loss calls)
+    is timed beside it.  cfg5 = B=16, 768x1280, fp16 tensors: 2 correlation calls on [16,256,96,160] on the f16
+    matrix cores with their 2 backward calls, 2 forward_warp of half flows, 4 full-resolution image_warp of half
+    images (core/flownet.py:27-70: the stacked nets warp at full resolution)."""
+    import torch
+    from unflow_amd import ops
+    from unflow_amd.image_warp import image_warp
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    gen = torch.Generator(device=dev)
+    lrelu = torch.nn.functional.leaky_relu
+    global H, W
+    if args.config == "cfg2":
+        B = 8 if args.batch == 32 else args.batch
+        gen.manual_seed(1234 + 2)
+        fa = lrelu(torch.randn((B, FEAT_C, H8, W8), device=dev, generator=gen), 0.1)
+        fb = lrelu(torch.randn((B, FEAT_C, H8, W8), device=dev, generator=gen), 0.1)
+        im1, im2 = smooth_images(torch, gen, B), smooth_images(torch, gen, B)
+        ffw = smooth_flow(torch, gen, B)
+        fbw = -ffw + 0.05 * smooth_flow(torch, gen, B)
+        parts = {"corr_fwd": lambda: (ops.correlation(fa, fb), ops.correlation(fb, fa)),
+                 "backward_warp": lambda: (ops.backward_warp(im2, ffw), ops.backward_warp(im1, fbw)),
+                 "image_warp": lambda: (image_warp(im2, ffw), image_warp(im1, fbw))}
+
+        def step():
+            with torch.no_grad():
+                parts["corr_fwd"]()
+                parts["backward_warp"]()
+        dtype, hh, ww = "f32", H, W
+        work = ("cfg2: 384x1280 pairs, batch %d: 2x FlowNetC correlation forward on [B,256,48,160] (fw and bw direction) + "
+                "bidirectional backward_warp (2 calls on [B,384,1280,3])" % B)
+        alg = {"corr_fwd": (2 * CORR_FWD_FLOP * B, 2 * CORR_FWD_BYTES * B), "backward_warp": (0, 2 * B * H * W * 32),
+               "image_warp": (0, 2 * B * H * W * 32)}
+        peak_tf = FP32_MATRIX_PEAK_TF
+    else:
+        B = 16 if args.batch == 32 else args.batch
+        hh, ww = 768, 1280
+        h8, w8 = hh // 8, ww // 8
+        gen.manual_seed(1234 + 5)
+        fa = lrelu(torch.randn((B, FEAT_C, h8, w8), device=dev, generator=gen), 0.1).half()
+        fb = lrelu(torch.randn((B, FEAT_C, h8, w8), device=dev, generator=gen), 0.1).half()
+        top_fw = torch.randn((B, D, h8, w8), device=dev, generator=gen).half()
+        top_bw = torch.randn((B, D, h8, w8), device=dev, generator=gen).half()
+        H, W = hh, ww                                   # smooth_images / smooth_flow build at the module's extents
+        im1, im2 = smooth_images(torch, gen, B).half(), smooth_images(torch, gen, B).half()
+        ffw32 = smooth_flow(torch, gen, B)
+        ffw, fbw = ffw32.half(), (-ffw32 + 0.05 * smooth_flow(torch, gen, B)).half()
+        del ffw32
+        H, W = 384, 1280
+        parts = {"corr_fwd": lambda: (ops.correlation_fp16(fa, fb), ops.correlation_fp16(fb, fa)),
+                 "corr_bwd": lambda: (ops.correlation_fp16_grad(top_fw, fa, fb), ops.correlation_fp16_grad(top_bw, fb, fa)),
+                 "forward_warp": lambda: (ops.forward_warp_fp16(ffw), ops.forward_warp_fp16(fbw)),
+                 "image_warp": lambda: (ops.image_warp_fp16(im2, ffw), ops.image_warp_fp16(im1, fbw),
+                                        ops.image_warp_fp16(im2, fbw), ops.image_warp_fp16(im1, ffw))}
+
+        def step():
+            with torch.no_grad():
+                for k in ("corr_fwd", "corr_bwd", "forward_warp", "image_warp"):
+                    parts[k]()
+        dtype = "f16 (f32 accumulate)"
+        work = ("cfg5: 768x1280 pairs, batch %d, fp16 tensors: 2x FlowNetC correlation fwd+bwd on [B,256,96,160] on the f16 "
+                "matrix cores, 2x forward_warp of half flows, 4x full-resolution image_warp of half images" % B)
+        fl = 2 * D * h8 * w8 * FEAT_C
+        alg = {"corr_fwd": (2 * fl * B, 2 * 2 * h8 * w8 * (2 * FEAT_C + D) * B),
+               "corr_bwd": (4 * fl * B, 2 * 2 * h8 * w8 * (D + 4 * FEAT_C) * B),
+               "forward_warp": (0, 2 * B * hh * ww * 8), "image_warp": (0, 4 * B * hh * ww * 16)}
+        peak_tf = F16_MATRIX_PEAK_TF
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    per = {}
+    with torch.no_grad():
+        for k, fn in parts.items():
+            ms = event_time(torch, fn, n=10, warm=2)
+            fl, by = alg[k]
+            per[k] = {"ms": ms, "hbm_gbs": by / (ms * 1e-3) / 1e9, "frac_of_8TBs": by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if fl:
+                per[k].update(tflops=fl / (ms * 1e-3) / 1e12, frac_of_matrix_peak=fl / (ms * 1e-3) / 1e12 / peak_tf)
+    dom = "corr_bwd" if "corr_bwd" in per else "corr_fwd"
+    # these kernels are priced against BOTH ceilings: on the f16 matrix cores the correlation's algorithmic
+    # traffic at 8 TB/s takes longer than its flops at the dense f16 peak, so cfg5 is HBM-bound
+    hbm_bound = per[dom]["frac_of_8TBs"] > per[dom].get("frac_of_matrix_peak", 0.0)
+    out = {"metric": "image-pairs/sec, BASELINE %s (informational; the headline is cfg3)" % args.config,
+           "value": B * args.steps / dt, "unit": "image-pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": dtype, "data": "synthetic", "informational": True,
+           "config": {"workload": work, "global_batch": B, "height": hh, "width": ww, "parallelism": "single GPU"},
+           "roofline": {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom + " (both calls of the step)",
+                        "achieved": per[dom]["hbm_gbs"] if hbm_bound else per[dom]["tflops"],
+                        "peak": HBM_PEAK_GBS if hbm_bound else peak_tf, "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                        "frac": per[dom]["frac_of_8TBs"] if hbm_bound else per[dom]["frac_of_matrix_peak"],
+                        "traffic": None, "frac_basis": "HIP events around the calls on the launch stream; algorithmic bytes / flops of SURVEY 8d",
+                        "parts": per}}
+    print(json.dumps(out))
+    return 0
+
+
 # ============================================================================= main
 def run_dry(args):
     """Launch-path rehearsal without a GPU: rendezvous, one all-reduce, one JSON line."""
@@ -465,6 +576,8 @@ def main():
         sys.exit(spawn_ranks(args))
     if args.dry:
         sys.exit(run_dry(args))
+    if args.config != "cfg3":
+        sys.exit(run_side_config(args))
 
     import numpy as np
     import torch
@@ -639,11 +752,15 @@ def breakdown(wl, fwd_ms, bwd_ms):
                  2 * CORR_BWD_BYTES * B))
     del cfw, cbw, fa_g, fb_g
     fah, fbh = wl.fa.half(), wl.fb.half()
-    rows.append(("corr_fwd, fp16 storage / f32 accumulate (extension)", timeit(lambda: ops.correlation_fp16(fah, fbh)),
+    rows.append(("corr_fwd, fp16 on the f16 matrix cores (extension)", timeit(lambda: ops.correlation_fp16(fah, fbh)),
                  CORR_FWD_BYTES * B // 2))
     toph = wl.top_fw.half()
-    rows.append(("corr_bwd, fp16 storage / f32 accumulate (extension)",
+    rows.append(("corr_bwd, fp16 on the f16 matrix cores (extension)",
                  timeit(lambda: ops.correlation_fp16_grad(toph, fah, fbh)), CORR_BWD_BYTES * B // 2))
+    rows.append(("corr_fwd, fp16 storage / f32 MFMA (exact form)", timeit(lambda: ops.correlation_fp16_exact(fah, fbh)),
+                 CORR_FWD_BYTES * B // 2))
+    rows.append(("corr_bwd, fp16 storage / f32 MFMA (exact form)",
+                 timeit(lambda: ops.correlation_fp16_grad(toph, fah, fbh, exact=True)), CORR_BWD_BYTES * B // 2))
     del toph, fah, fbh
     rows.append(("image_warp C3", timeit(lambda: image_warp(wl.im2, ffw)), npx * 32))
     rows.append(("image_warp C2", timeit(lambda: image_warp(fbw, ffw)), npx * 24))

@@ -36,12 +36,16 @@ extern "C" {
 #define UNFLOW_ERR_INVALID_ARGUMENT 1 /* tf errors::InvalidArgument */
 #define UNFLOW_ERR_LAUNCH 2           /* hipGetLastError() after a launch */
 
-#define UNFLOW_ABI_VERSION 3
+#define UNFLOW_ABI_VERSION 4
 
 typedef void *unflow_stream_t; /* hipStream_t */
 
 int unflow_abi_version(void);
 const char *unflow_last_error(void);
+/* "" for a production build; otherwise the UNFLOW_TUNE_* diagnostic knobs the kernels were compiled with
+ * (tools/variants.sh: timing-only builds, some of which compute WRONG results).  The Python binding refuses
+ * to load a library whose flags are not empty unless UNFLOW_ALLOW_DIAGNOSTIC_BUILD=1. */
+const char *unflow_build_flags(void);
 
 /* Measurement helper, not part of the reference's path: dst[0..bytes) = src[0..bytes) with a
  * hand-written 16-byte-per-lane streaming copy.  bench.py prices the HBM-bound kernels
@@ -59,7 +63,10 @@ int unflow_correlation_geometry(int H, int W, int kernel_size, int max_displacem
 /* Replaces Correlation() (ops/correlation_op.cu.cc:250-315; op at
  * ops/correlation_op.cc:43-85).  in0,in1 [B,C,H,W]; out [B,D,Ho,Wo].
  * padded0/padded1 [B,H+2p,W+2p,C] are the op's outputs 1 and 2; pass NULL for
- * both to skip materialising them (the kernels never read them). */
+ * both to skip materialising them (the kernels never read them).
+ * Speed: the matrix-core kernels serve the FlowNetC attributes only (kernel_size 1, stride_1 1,
+ * stride_2 2, max_displacement = pad = 20: core/flownet.py:221-222, the only call site of the op
+ * in the reference); every other attribute set is computed by one-lane-per-element kernels. */
 int unflow_correlation_fwd(const float *in0, const float *in1, float *out, float *padded0,
                            float *padded1, int B, int C, int H, int W, int kernel_size,
                            int max_displacement, int pad, int stride_1, int stride_2,

@@ -342,6 +342,10 @@ def test_warps_fp16_storage(oracle_mod, dev, B, H, W, C):
         ops.image_warp_fp16(torch.from_numpy(im32).to(dev), torch.from_numpy(flow).to(dev))
     with pytest.raises(ValueError, match="channels"):
         ops.image_warp_fp16(torch.zeros((1, 4, 4, 5), dtype=torch.float16, device=dev), torch.zeros((1, 4, 4, 2), dtype=torch.float16, device=dev))
+    with pytest.raises(ValueError, match="single-pixel"):      # its 8-byte tap would reach in front of the tensor
+        ops.image_warp_fp16(torch.zeros((1, 1, 1, 3), dtype=torch.float16, device=dev), torch.zeros((1, 1, 1, 2), dtype=torch.float16, device=dev))
+    one = ops.image_warp_fp16(torch.ones((1, 1, 2, 3), dtype=torch.float16, device=dev), torch.zeros((1, 1, 2, 2), dtype=torch.float16, device=dev))
+    assert torch.equal(one, torch.ones_like(one))
     # a half tensor at an odd half (2-byte aligned only) is refused, not read with 4-byte accesses
     big = torch.zeros(B * H * W * 2 + 1, dtype=torch.float16, device=dev)
     odd = big[1:].view(B, H, W, 2)

@@ -127,3 +127,14 @@ def test_matrix_kernels_keep_their_accumulators_in_registers(tmp_path):
     assert all(s <= 128 for s in worst.values()), worst
     hot = [s for n, s in zip(names, scratch) if "fwd_half_kernelILi4ELb0" in n or "bwd2" in n]
     assert len(hot) == 3 and max(hot) <= 64, list(zip(names, scratch))
+
+
+def test_the_shipped_library_is_not_a_diagnostic_build():
+    """unflow_build_flags() lists the UNFLOW_TUNE_* knobs the kernels were compiled with (tools/variants.sh builds
+    timing-only variants, some with wrong results); the shipped build has none, and the loader refuses one that has."""
+    import ctypes
+    from unflow_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.unflow_build_flags.restype = ctypes.c_char_p
+    assert lib.unflow_build_flags() == b""
+    assert "UNFLOW_ALLOW_DIAGNOSTIC_BUILD" in open(_lib.__file__).read()

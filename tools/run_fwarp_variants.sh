@@ -1,3 +1,4 @@
+export UNFLOW_ALLOW_DIAGNOSTIC_BUILD=1   # the variants are diagnostic builds (unflow_build_flags())
 mkdir -p gpurun_out
 out=gpurun_out/fwarp_variants_${1:-run}.txt
 timeout -k 10 200 python tools/fwarp_variant.py default >> $out 2>gpurun_out/variants_err.log || echo "default FAILED" >> $out

@@ -1,3 +1,4 @@
+export UNFLOW_ALLOW_DIAGNOSTIC_BUILD=1   # the variants are diagnostic builds (unflow_build_flags())
 # On the GPU box: one line per build in unflow_amd/variants (and the default build first).
 mkdir -p gpurun_out
 out=gpurun_out/variants_${1:-run}.txt

@@ -10,6 +10,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["UNFLOW_HIP_LIB"] = os.path.abspath(sys.argv[1])
+os.environ["UNFLOW_ALLOW_DIAGNOSTIC_BUILD"] = "1"   # a stamps build is a diagnostic build
 import torch  # noqa: E402
 from unflow_amd import _lib, ops  # noqa: E402
 

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # kernel with -D knobs); never a fallback -- a missing file raises like the default path does.
 LIB_PATH = os.environ.get("UNFLOW_HIP_LIB") or os.path.join(_HERE, "libunflow_hip.so")
 
-ABI_VERSION = 3      # UNFLOW_ABI_VERSION of include/unflow_hip.h
+ABI_VERSION = 4      # UNFLOW_ABI_VERSION of include/unflow_hip.h
 UNFLOW_OK = 0
 UNFLOW_ERR_INVALID_ARGUMENT = 1
 UNFLOW_ERR_LAUNCH = 2
@@ -27,6 +27,7 @@ _LL = ctypes.c_longlong
 SIGNATURES = {
     "unflow_abi_version": (_I, []),
     "unflow_last_error": (ctypes.c_char_p, []),
+    "unflow_build_flags": (ctypes.c_char_p, []),
     "unflow_stream_copy": (_I, [_P, _P, ctypes.c_size_t, _P]),
     "unflow_correlation_geometry": (_I, [_I, _I, _I, _I, _I, _I, _I, ctypes.POINTER(_I)]),
     "unflow_correlation_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -99,6 +100,11 @@ def load():
             fn.argtypes = args
         if lib.unflow_abi_version() != ABI_VERSION:
             raise UnflowLibraryError("libunflow_hip.so ABI version mismatch")
+        flags = lib.unflow_build_flags().decode().strip()
+        if flags and os.environ.get("UNFLOW_ALLOW_DIAGNOSTIC_BUILD") != "1":
+            # a timing-only variant (tools/variants.sh), some of which compute wrong results on purpose
+            raise UnflowLibraryError("%s is a diagnostic build (%s): set UNFLOW_ALLOW_DIAGNOSTIC_BUILD=1 to load it"
+                                     % (LIB_PATH, flags))
         _lib = lib
     return _lib
 

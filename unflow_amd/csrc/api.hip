@@ -57,4 +57,13 @@ extern "C" int unflow_stream_copy(const void *src, void *dst, size_t bytes, unfl
 }
 
 extern "C" int unflow_abi_version(void) { return UNFLOW_ABI_VERSION; }
+extern "C" const char *unflow_build_flags(void) {
+  static char buf[256] = {0};
+  static bool done = false;
+  if (!done) {      // idempotent: both parts are string literals
+    snprintf(buf, sizeof(buf), "%s%s", unflow::tune_flags_correlation_mfma(), unflow::tune_flags_warp());
+    done = true;
+  }
+  return buf;
+}
 extern "C" const char *unflow_last_error(void) { return unflow::error_buffer(); }

@@ -108,76 +108,84 @@ __global__ __launch_bounds__(256) void corr_fwd_generic_kernel(const float *__re
   }
 }
 
-#define ROUND_OFF 50000  // ops/correlation_op.cu.cc:19
+// Integer division that rounds towards -inf / +inf for a positive divisor (the numerators below go negative
+// inside the padding, where C's truncation towards zero would be wrong).
+__device__ inline int div_floor(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+__device__ inline int div_ceil(int a, int b) { return -div_floor(-a, b); }
 
-// One lane per input element (b,c,y,x), x fastest; computes both gradients with
-// the reference's output-range arithmetic (ops/correlation_op.cu.cc:133-142,
-// :211-224).
+// Output positions whose k-wide patch (origin o * stride_1 + max_displacement in padded coordinates) covers
+// the padded coordinate q along one axis:  o * stride_1 + j == q - max_displacement  for a tap j in [0, k).
+struct Span {
+  int lo, hi;   // inclusive, clamped to [0, n_out); empty when lo > hi
+};
+__device__ inline Span covering_outputs(int q_minus_md, int k, int stride_1, int n_out) {
+  Span s;
+  s.lo = max(0, div_ceil(q_minus_md - (k - 1), stride_1));
+  s.hi = min(n_out - 1, div_floor(q_minus_md, stride_1));
+  return s;
+}
+
+// sum of one displacement plane of the upstream gradient over a rectangle of output positions
+__device__ inline float box_sum(const float *__restrict__ dplane, int out_w, Span ys, Span xs, float partner, float acc) {
+  for (int y = ys.lo; y <= ys.hi; ++y)
+    for (int x = xs.lo; x <= xs.hi; ++x) acc = fmaf(dplane[(long long)y * out_w + x], partner, acc);
+  return acc;
+}
+
+// Both gradients for attributes the matrix-core path does not take (kernel_size > 1, stride_1 > 1, ...): one lane
+// per input element (b, c, y, x), x fastest.  With (yq, xq) the element's padded coordinates and
+// t = (dy, dx) * stride_2 a displacement, the forward (ops/correlation_op.cu.cc:51-117) pairs first[yq, xq] with
+// second[yq + t] in every output position whose patch covers (yq, xq), and second[yq, xq] with first[yq - t] in
+// every output position whose patch covers (yq, xq) - t.  Hence
+//   d first[yq, xq]  = 1/(k*k*C) * sum_t second[(yq, xq) + t] * sum_{o covers (yq, xq)}     top[t, o]
+//   d second[yq, xq] = 1/(k*k*C) * sum_t first[(yq, xq) - t]  * sum_{o covers (yq, xq) - t} top[t, o]
+// -- the sums the reference's CorrelateDataBackward0 / 1 evaluate (ops/correlation_op.cu.cc:119-248).
 __global__ __launch_bounds__(256) void corr_bwd_generic_kernel(const float *__restrict__ topdiff,
                                                                const float *__restrict__ in0,
                                                                const float *__restrict__ in1,
                                                                float *__restrict__ g0, float *__restrict__ g1,
                                                                CorrGeometry g, int C, long long total) {
-  const int topwidth = g.out_width, topheight = g.out_height, topchannels = g.out_channels;
-  const int kr = g.kernel_radius, s1 = g.stride_1, s2 = g.stride_2, md = g.max_displacement;
-  const int ngr = g.grid_radius, ngw = g.grid_width;
-  const int round_off = ROUND_OFF, round_off_s1 = s1 * round_off;
-  const long long plane = (long long)g.H * g.W;
-  const long long topplane = (long long)topheight * topwidth;
-  const float inv = 1.f / (float)((kr * 2 + 1) * (kr * 2 + 1) * C);
+  const int out_w = g.out_width, out_h = g.out_height;
+  const int k = g.kernel_size, s1 = g.stride_1, s2 = g.stride_2, md = g.max_displacement;
+  const int radius = g.grid_radius, gw = g.grid_width;
+  const long long plane = (long long)g.H * g.W, out_plane = (long long)out_h * out_w;
+  const float scale = 1.f / (float)(k * k * C);
   for (long long idx = blockIdx.x * 256LL + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int lx = (int)(idx % g.W);
-    long long t = idx / g.W;
-    const int my = (int)(t % g.H);
-    t /= g.H;
-    const int n = (int)(t % C);
-    const long long item = t / C;
-    const int l = lx + g.pad, m = my + g.pad;
-    const float *td = topdiff + item * topchannels * topplane;
-    const float *p0 = in0 + (item * C + n) * plane;
-    const float *p1 = in1 + (item * C + n) * plane;
+    const int x = (int)(idx % g.W);
+    long long rest = idx / g.W;
+    const int y = (int)(rest % g.H);
+    rest /= g.H;
+    const int c = (int)(rest % C);
+    const long long item = rest / C;
+    const int xq = x + g.pad, yq = y + g.pad;
+    const float *top = topdiff + item * g.out_channels * out_plane;
+    const float *first = in0 + (item * C + c) * plane;
+    const float *second = in1 + (item * C + c) * plane;
 
-    float sum0 = 0.f;
-    {
-      int xmin = (l - 2 * kr - md + round_off_s1 - 1) / s1 + 1 - round_off;
-      int ymin = (m - 2 * kr - md + round_off_s1 - 1) / s1 + 1 - round_off;
-      int xmax = (l - md + round_off_s1) / s1 - round_off;
-      int ymax = (m - md + round_off_s1) / s1 - round_off;
-      if (xmax >= 0 && ymax >= 0 && xmin <= topwidth - 1 && ymin <= topheight - 1) {
-        xmin = max(0, xmin);
-        xmax = min(topwidth - 1, xmax);
-        ymin = max(0, ymin);
-        ymax = min(topheight - 1, ymax);
-        for (int p = -ngr; p <= ngr; ++p)
-          for (int o = -ngr; o <= ngr; ++o) {
-            const float bot1tmp = load_padded(p1, m + s2 * p, l + s2 * o, g.pad, g.H, g.W);
-            const float *tp = td + (long long)((p + ngr) * ngw + (o + ngr)) * topplane;
-            for (int y = ymin; y <= ymax; ++y)
-              for (int x = xmin; x <= xmax; ++x) sum0 = fmaf(tp[(long long)y * topwidth + x], bot1tmp, sum0);
-          }
+    // wrt the first input: the covering rectangle does not depend on the displacement
+    float d_first = 0.f;
+    const Span ys0 = covering_outputs(yq - md, k, s1, out_h), xs0 = covering_outputs(xq - md, k, s1, out_w);
+    if (ys0.lo <= ys0.hi && xs0.lo <= xs0.hi) {
+      for (int dy = -radius; dy <= radius; ++dy)
+        for (int dx = -radius; dx <= radius; ++dx) {
+          const float partner = load_padded(second, yq + s2 * dy, xq + s2 * dx, g.pad, g.H, g.W);
+          d_first = box_sum(top + (long long)((dy + radius) * gw + (dx + radius)) * out_plane, out_w, ys0, xs0, partner, d_first);
+        }
+    }
+    // wrt the second input: the rectangle moves with the displacement
+    float d_second = 0.f;
+    for (int dy = -radius; dy <= radius; ++dy) {
+      const Span ys = covering_outputs(yq - md - s2 * dy, k, s1, out_h);
+      if (ys.lo > ys.hi) continue;
+      for (int dx = -radius; dx <= radius; ++dx) {
+        const Span xs = covering_outputs(xq - md - s2 * dx, k, s1, out_w);
+        if (xs.lo > xs.hi) continue;
+        const float partner = load_padded(first, yq - s2 * dy, xq - s2 * dx, g.pad, g.H, g.W);
+        d_second = box_sum(top + (long long)((dy + radius) * gw + (dx + radius)) * out_plane, out_w, ys, xs, partner, d_second);
       }
     }
-    float sum1 = 0.f;
-    for (int p = -ngr; p <= ngr; ++p)
-      for (int o = -ngr; o <= ngr; ++o) {
-        const int s2o = s2 * o, s2p = s2 * p;
-        int xmin = (l - 2 * kr - md - s2o + round_off_s1 - 1) / s1 + 1 - round_off;
-        int ymin = (m - 2 * kr - md - s2p + round_off_s1 - 1) / s1 + 1 - round_off;
-        int xmax = (l - md - s2o + round_off_s1) / s1 - round_off;
-        int ymax = (m - md - s2p + round_off_s1) / s1 - round_off;
-        if (xmax >= 0 && ymax >= 0 && xmin <= topwidth - 1 && ymin <= topheight - 1) {
-          xmin = max(0, xmin);
-          xmax = min(topwidth - 1, xmax);
-          ymin = max(0, ymin);
-          ymax = min(topheight - 1, ymax);
-          const float bot0tmp = load_padded(p0, m - s2p, l - s2o, g.pad, g.H, g.W);
-          const float *tp = td + (long long)((p + ngr) * ngw + (o + ngr)) * topplane;
-          for (int y = ymin; y <= ymax; ++y)
-            for (int x = xmin; x <= xmax; ++x) sum1 = fmaf(tp[(long long)y * topwidth + x], bot0tmp, sum1);
-        }
-      }
-    g0[idx] = sum0 * inv;
-    g1[idx] = sum1 * inv;
+    g0[idx] = d_first * scale;
+    g1[idx] = d_second * scale;
   }
 }
 

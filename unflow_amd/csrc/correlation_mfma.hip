@@ -1365,13 +1365,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
       const int idx = (int)threadIdx.x + NTHREADS * q;
       const int oy = 4 * t + st_rr;
       const int x = S * xs0 + st_c4 * 4;
-      if (oy < hs && x < W) {                    // C % 128 == 0: every channel exists
-        f32x4 v = *reinterpret_cast<const f32x4 *>(ob + idx * 4);
-        if (pow2_c) v *= inv_c;
-        else v /= (float)C;
-        const int soff = (int)(((long long)(NTHREADS / 16) * q * plane + (long long)(S * 4 * t + cy) * W + S * xs0) * 4);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, st_voff, soff, 0);
-      }
+      // Every lane of every wave issues the store: the row barrier counts on exactly four stores per wave
+      // behind the last DMA piece (vmcnt(4)).  A lane outside the image gets an out-of-range VECTOR offset,
+      // which the descriptor's range check drops (C % 128 == 0: every channel exists).
+      f32x4 v = *reinterpret_cast<const f32x4 *>(ob + idx * 4);
+      if (pow2_c) v *= inv_c;
+      else v /= (float)C;
+      const int soff = (int)(((long long)(NTHREADS / 16) * q * plane + (long long)(S * 4 * t + cy) * W + S * xs0) * 4);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (oy < hs && x < W) ? st_voff : (int)OOB, soff, 0);
     };
 
     RowState rs = row_state(0);
@@ -1699,6 +1700,32 @@ int corr_mfma_bwd_f16(const void *topdiff, const void *in0, const void *in1, voi
   else UNFLOW_LAUNCH16(false);
 #undef UNFLOW_LAUNCH16
   return launch_status("correlation_bwd (fp16 storage)");
+}
+
+const char *tune_flags_correlation_mfma() {
+  return ""
+#ifdef UNFLOW_TUNE_STAMPS
+         " UNFLOW_TUNE_STAMPS"
+#endif
+#ifdef UNFLOW_TUNE_FWD_NODMA
+         " UNFLOW_TUNE_FWD_NODMA"
+#endif
+#ifdef UNFLOW_TUNE_FWD_NOSTORE
+         " UNFLOW_TUNE_FWD_NOSTORE"
+#endif
+#ifdef UNFLOW_TUNE_NODMA
+         " UNFLOW_TUNE_NODMA"
+#endif
+#ifdef UNFLOW_TUNE_NOMFMA
+         " UNFLOW_TUNE_NOMFMA"
+#endif
+#ifdef UNFLOW_TUNE_NOSTORE
+         " UNFLOW_TUNE_NOSTORE"
+#endif
+#ifdef UNFLOW_TUNE_OLD_BWD
+         " UNFLOW_TUNE_OLD_BWD"
+#endif
+      ;
 }
 
 }  // namespace unflow

@@ -365,10 +365,12 @@ __device__ inline void nt_store_px(const float (&r)[C], _Float16 *p) {
   }
 }
 
-#ifndef UNFLOW_TUNE_PPL
-#define UNFLOW_TUNE_PPL 2   // measured at B=32 384x1280 C=3: 1 -> 5.3, 2 -> 5.9, 4 -> 5.8, 8 -> 1.8 TB/s (backward_warp)
+// pixels per lane; measured at B=32 384x1280 C=3: 1 -> 5.3, 2 -> 5.9, 4 -> 5.8, 8 -> 1.8 TB/s (backward_warp)
+#ifdef UNFLOW_TUNE_PPL
+constexpr int kPPL = UNFLOW_TUNE_PPL;            // diagnostic build (tools/run_warp_variants.sh)
+#else
+constexpr int kPPL = 2;
 #endif
-constexpr int kPPL = UNFLOW_TUNE_PPL;            // pixels per lane
 constexpr int kFastTileH = kTileH * kPPL;        // 16 rows
 struct FastTile {
   int x, y0;          // lane's column, first row (rows y0 + 4 i)
@@ -1149,6 +1151,20 @@ int check_dims(const char *op, int B, int H, int W, int C) {
 }
 
 }  // namespace
+const char *tune_flags_warp() {
+  return ""
+#ifdef UNFLOW_TUNE_PPL
+         " UNFLOW_TUNE_PPL"
+#endif
+#ifdef UNFLOW_TUNE_NOFAST
+         " UNFLOW_TUNE_NOFAST"
+#endif
+#ifdef UNFLOW_TUNE_FW_STAMPS
+         " UNFLOW_TUNE_FW_STAMPS"
+#endif
+      ;
+}
+
 }  // namespace unflow
 
 using namespace unflow;
@@ -1315,6 +1331,10 @@ static int check_f16(const char *what, int B, int H, int W, int C) {
   if (int rc = check_dims(what, B, H, W, C)) return rc;
   if ((long long)B * H * W != 0 && !fast_ok(B, H, W, C))
     return fail(UNFLOW_ERR_INVALID_ARGUMENT, "%s (fp16 storage): 1 <= channels <= 3 and H*W*3 < 2^30 required", what);
+  // C == 3: a pixel is read as a 4-byte aligned 8-byte access that reaches one half beyond it; at the tensor's
+  // last pixel it reaches BACKWARDS instead -- which for a one-pixel tensor would be in front of the allocation
+  if (C == 3 && (long long)B * H * W == 1)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "%s (fp16 storage): a single-pixel 3-channel tensor is not supported", what);
   return UNFLOW_OK;
 }
 static bool aligned4(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 3) == 0; }

@@ -16,15 +16,25 @@ class GraphedStep:
     returns the same output tensors, overwritten in place."""
 
     def __init__(self, fn, warmup=2):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):          # warm-up off the default stream, as capture requires
-            for _ in range(warmup):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.outputs = fn()
+        # The leaves of fn's autograd graph were created on the caller's stream while warm-up and capture run on
+        # side streams (capture requires it): the gradient accumulation then crosses streams BY DESIGN -- the
+        # streams are joined explicitly below -- so autograd's warning about it is switched off for this scope.
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):          # warm-up off the default stream, as capture requires
+                for _ in range(warmup):
+                    fn()
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.outputs = fn()
+        finally:
+            if quiet is not None:
+                quiet(True)
 
     def replay(self):
         self.graph.replay()
