@@ -264,8 +264,8 @@ def test_bench_loss_leg_cfg3(oracle_mod, dev):
     composed = (losses.ternary_loss(wl.im1, image_warp(wl.im2, ffw), m_fw, 3, norm_count=npx) +
                 losses.ternary_loss(wl.im2, image_warp(wl.im1, fbw), m_bw, 3, norm_count=npx))
     composed.backward()
-    np.testing.assert_allclose(fused, float(composed), rtol=1e-6)
-    assert float(wl.composed_loss()) == float(composed)           # what bench.py asserts in every run
+    np.testing.assert_allclose(fused, float(composed.detach()), rtol=1e-6)
+    assert float(wl.composed_loss()) == float(composed.detach())           # what bench.py asserts in every run
     for got, want in ((g_fw, ffw.grad), (g_bw, fbw.grad)):
         scale = float(want.abs().max())
         assert scale > 0

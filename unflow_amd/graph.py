@@ -10,6 +10,16 @@ executor running a static graph; this is its MI355X counterpart.
 import torch
 
 
+def _detached(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach()
+    if isinstance(x, (tuple, list)):
+        return type(x)(_detached(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _detached(v) for k, v in x.items()}
+    return x
+
+
 class GraphedStep:
     """Capture ``fn()`` (which reads fixed input tensors and returns tensors) into a
     HIP graph.  ``replay()`` re-runs it on the current contents of those inputs and
@@ -31,7 +41,11 @@ class GraphedStep:
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.outputs = fn()
+                out = fn()
+            # Replays need the output BUFFERS, not the autograd graph behind them: dropping it here also frees the
+            # gradient accumulators that were created on the capture stream, so that a later eager backward of the
+            # same leaves (on the caller's stream) does not meet them.
+            self.outputs = _detached(out)
         finally:
             if quiet is not None:
                 quiet(True)
