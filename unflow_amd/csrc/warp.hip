@@ -636,6 +636,14 @@ constexpr float kUnfix = 1.f / 2097152.f;
 static_assert(kSX * kSY <= 1024, "fixed-point headroom assumes <= 1024 source pixels per window");
 static_assert(kWW * kWH <= kWinCells, "fallback window must fit");
 
+// float -> fixed point, round to nearest (ties up): ONE instruction, v_cvt_rpi_i32_f32 = floor(x + 0.5)
+// (rintf + a conversion are two); x >= 0 here
+__device__ inline unsigned fix_round(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return (unsigned)r;
+}
+
 __device__ inline float gauss(float d) {   // exp(-d*d/2) through v_exp_f32
   return __builtin_amdgcn_exp2f(d * d * -0.72134752044448170368f);
 }
@@ -734,7 +742,21 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
     const int lx0 = w.min_x - wx0, ly0 = w.min_y - wy0;
     const int nx = w.max_x - w.min_x, ny = w.max_y - w.min_y;   // taps - 1 per axis (<= 8)
     const bool inside = lx0 >= 0 && lx0 + nx < ww && ly0 >= 0 && ly0 + ny < wh;
-    if (inside) {
+    // floor(t + 4) - floor(t - 4) = 8 for every t: a patch that the image border does not clip has 9 x 9 taps.
+    // When that holds for every lane of the wave (all but the waves at the image border) the taps need no
+    // per-tap predicate: multiply, round, add -- 2 vector instructions per tap instead of 8 (profiles/
+    // r03_pmc_loss.txt showed 72 % VALU issue for the predicated loop).  The kernel's time did not move
+    // (0.377 ms either way): it is bound by the LDS atomics themselves, as DESIGN 4.3 says.
+    if (__builtin_amdgcn_ballot_w64(!(inside && nx == 8 && ny == 8)) == 0) {
+      unsigned *wp = win + ly0 * ww + lx0;
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const float ey = gauss((float)(w.min_y + r) - w.ty) * kFix;
+#pragma unroll
+        for (int a = 0; a < 9; ++a) atomicAdd(wp + a, fix_round(ex[a] * ey));
+        wp += ww;
+      }
+    } else if (inside) {
       unsigned *wp = win + ly0 * ww + lx0;
 #pragma unroll
       for (int r = 0; r < 9; ++r) {
@@ -742,7 +764,7 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
         const float ey = gauss((float)(w.min_y + r) - w.ty) * kFix;
 #pragma unroll
         for (int a = 0; a < 9; ++a)
-          if (a <= nx) atomicAdd(wp + r * ww + a, (unsigned)__float2uint_rn(ex[a] * ey));
+          if (a <= nx) atomicAdd(wp + r * ww + a, fix_round(ex[a] * ey));
       }
     } else {
       for (int r = 0; r <= ny; ++r) {
@@ -756,7 +778,7 @@ __global__ __launch_bounds__(kSplatThreads) void forward_warp_fwd_kernel(const F
           const float weight = ex[a] * ey;
           const int lx = lx0 + a;
           if (rowin && lx >= 0 && lx < ww)
-            atomicAdd(&win[ly * ww + lx], (unsigned)__float2uint_rn(weight * kFix));
+            atomicAdd(&win[ly * ww + lx], fix_round(weight * kFix));
           else
             unsafeAtomicAdd(out + (long long)n_y * W + w.min_x + a, weight);
         }
