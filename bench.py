@@ -394,6 +394,61 @@ def warps_roofline(wl, copy_gbs):
     return rows
 
 
+def loss_kernels_roofline(wl, copy_gbs):
+    """The loss kernels of the step, each against the ceiling that bounds it (in-run HIP-event times at the step's batch):
+      * soft census forward / backward, fused with the warp (ternary_*_pair_kernel<3,16,true>): VALU ISSUE.  A wave walks
+        19 rows x 24 pair taps x 3 transcendentals (8 issue cycles each) among `valu_insts_per_wave` vector instructions
+        (4 cycles each; the count is the PMC's SQ_INSTS_VALU / SQ_WAVES of profiles/r03_pmc_loss.json); floor = that
+        issue time over 1024 SIMDs at 2.4 GHz.  `pmc_valu_issue_frac` is the measured SQ_ACTIVE_INST_VALU share.
+      * forward_warp: LDS integer atomics.  floor = 81 taps per source pixel as wave instructions x 5.3 cycles (the
+        conflict-free ds_add_u32 rate per CU, profiles/ubench_lds_atomic.txt) over 256 CUs.
+      * fb-occlusion (+ warp of the other flow) and the sym reduction: HBM, algorithmic bytes / time."""
+    from unflow_amd import losses, ops
+    torch = wl.torch
+    B = wl.B
+    npx = B * H * W
+    ffw, fbw = wl.flow_fw.detach(), wl.flow_bw.detach()
+    pmc = {}
+    path = os.path.join(ROOT, "profiles", "r03_pmc_loss.json")
+    if os.path.exists(path):
+        with open(path) as fh:
+            pmc = json.load(fh)
+    clock = 2.4e9
+    rows = {}
+    f = ffw.clone().requires_grad_(True)
+
+    def census_fwd():
+        return losses.ternary_loss_warped(wl.im1, wl.im2, f, wl.border, max_distance=3)
+    ms_f = event_time(torch, census_fwd, n=10, warm=2)
+    loss = census_fwd()
+    ms_b = event_time(torch, lambda: torch.autograd.grad(loss, f, retain_graph=True), n=10, warm=2)
+    for name, ms, key in (("census_fwd_fused_warp", ms_f, "ternary_fwd_pair_kernel<3, 16, true>"),
+                          ("census_bwd_fused_warp", ms_b, "ternary_bwd_pair_kernel<3, 16, true>")):
+        rec = pmc.get(key, {})
+        ipw = rec.get("valu_insts_per_wave")
+        row = {"ms": ms, "bound": "valu issue", "pmc_valu_issue_frac": rec.get("valu_issue_frac"),
+               "pmc_source": "profiles/r03_pmc_loss.json" if rec else None}
+        if ipw:
+            trans = 19 * 24 * 3
+            floor_ms = rec["waves"] * ((ipw - trans) * 4 + trans * 8) / 1024 / clock * 1e3 * (B / 32.0)
+            row.update(valu_insts_per_wave=ipw, transcendentals_per_wave=trans, floor_ms=floor_ms, frac=floor_ms / ms)
+        rows[name] = row
+    ms = event_time(torch, lambda: ops.forward_warp(ffw), n=10, warm=2)
+    floor_ms = (npx / 64) * 81 * 5.3 / 256 / clock * 1e3
+    rows["forward_warp"] = {"ms": ms, "bound": "lds integer atomics", "floor_ms": floor_ms, "frac": floor_ms / ms,
+                            "model": "81 taps/pixel as ds_add_u32 wave instructions x 5.3 cycles per CU (conflict free), 256 CUs, 2.4 GHz"}
+    m = wl.border.clone()
+    ms = event_time(torch, lambda: losses.fb_occlusion_warp(ffw, fbw, m, mask_in=wl.border), n=10, warm=2)
+    gbs = npx * 24 / (ms * 1e-3) / 1e9
+    rows["fb_occlusion_warp"] = {"ms": ms, "bound": "hbm", "bytes_per_px": 24, "gbs": gbs, "frac_of_copy": gbs / copy_gbs,
+                                 "frac": gbs / HBM_PEAK_GBS}
+    dens = ops.forward_warp(fbw)
+    ms = event_time(torch, lambda: losses.sym_loss(m, dens, norm_count=npx), n=10, warm=2)
+    gbs = npx * 8 / (ms * 1e-3) / 1e9
+    rows["sym_loss"] = {"ms": ms, "bound": "hbm", "bytes_per_px": 8, "gbs": gbs, "frac_of_copy": gbs / copy_gbs, "frac": gbs / HBM_PEAK_GBS}
+    return rows
+
+
 def kitti_config_step(wl):
     """The reference's default KITTI loss (config_template/config.ini:79,98,123,166-174): 5-level
     pyramid H/4..H/64, ternary + 3 smooth_2nd + 0.2 fb + 12.4 occ, fb occlusion masks, fwd+bwd to
@@ -424,9 +479,9 @@ def kitti_config_step(wl):
 def traffic_record():
     """HBM bytes of the dominant kernel from PMC counters.  bench.py cannot sit under
     ``rocprofv3 --pmc`` and time itself, so the counters come from a separate pass
-    (tools/traffic_pmc.sh -> profiles/r02_traffic.json); the record carries the hash of the
+    (tools/profile_round.sh -> profiles/r03_traffic.json); the record carries the hash of the
     kernel source it was collected on and is only used when that is the source of this build."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
     src = os.path.join(ROOT, "unflow_amd", "csrc", "correlation_mfma.hip")
     if not (os.path.exists(path) and os.path.exists(src)):
         return None, None
@@ -434,10 +489,10 @@ def traffic_record():
         rec = json.load(fh)
     sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
     if rec.get("kernel_source_sha16") != sha:
-        return None, {"file": "profiles/r02_traffic.json", "stale": True,
+        return None, {"file": "profiles/r03_traffic.json", "stale": True,
                       "note": "collected on another version of correlation_mfma.hip: not reported"}
     return rec["corr_bwd_both_launches"]["hbm_bytes"], {
-        "file": "profiles/r02_traffic.json", "kernel_source_sha16": sha,
+        "file": "profiles/r03_traffic.json", "kernel_source_sha16": sha,
         "how": "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/traffic_pmc.sh), FETCH_SIZE doubled "
                "(gfx950), per call = both gradient launches; not measured in this run"}
 
@@ -688,7 +743,7 @@ def main():
                          "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP32_MATRIX_PEAK_TF,
                          "frac_basis": "HIP events around the call on the launch stream, mean over the timed region "
-                                       "(rocprofv3 kernel averages of the same command: profiles/r02_bench_kernel_stats.csv)",
+                                       "(rocprofv3 kernel averages of the same command: profiles/r03_bench_kernel_stats.csv)",
                          "traffic": traffic, "traffic_source": traffic_src,
                          "stream_copy_gbs": copy_gbs,
                          "avg_launch_ms": bwd_ms,
@@ -712,6 +767,7 @@ def main():
                 warps_roofline(wl, copy_gbs), bound="hbm",
                 note="algorithmic bytes / HIP-event time at B=%d; frac_of_copy is against stream_copy_gbs "
                      "(hand-written float4 copy, 1 GiB), frac_of_8TBs against the nominal HBM peak" % args.batch)
+            out["roofline"]["loss_kernels"] = loss_kernels_roofline(wl, copy_gbs)
             out["extension_bidirectional_correlation"] = {
                 "note": "NOT the headline: the same step when the caller obtains the (b,a) cost volume as a bit-exact "
                         "re-indexing of the (a,b) one and runs one backward call for both directions "
