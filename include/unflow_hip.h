@@ -129,6 +129,35 @@ int unflow_downsample_fwd(const float *images, float *output, int B, int H, int 
  *   norm_count: the charbonnier normalisation (losses.py:311-312); 0 means the
  *              local B*H*W, a batch shard passes the GLOBAL pixel count. */
 size_t unflow_reduce_workspace_floats(int B, int H, int W);
+
+/* Deferred reductions (launch-bound loss pyramids: core/unsupervised.py:114-141 evaluates ~40 scalar losses per
+ * step).  Between unflow_reduce_plan_begin(plan) and unflow_reduce_plan_end() the loss forwards of THIS thread
+ * (unflow_ternary_loss_fwd, unflow_ternary_loss_warp_fwd, unflow_sym_loss_fwd, unflow_charbonnier_fwd,
+ * unflow_smoothness_loss_fwd, unflow_gradient_loss_fwd) do not launch their final one-block reduction and do not
+ * write *loss: they append (workspace, number of partial sums, 1 / norm) to the caller-owned plan.
+ * unflow_reduce_plan_run then reduces all segments in ONE launch (one block each, the same fixed order and double
+ * accumulation as the immediate form: results[i] is bit-identical) and folds them in a second one-block launch:
+ *   total = sum_i coeff[i] * results[i],   per_term[t] = sum_{i: term[i] == t} term_weight[i] * results[i]  (t < 8).
+ * coeff / term / term_weight are HOST arrays of plan->n entries (copied into the kernel arguments); results
+ * (plan->n floats), total (1) and per_term (8) are device buffers.  At most UNFLOW_PLAN_CAPACITY segments; the
+ * workspaces must stay untouched until the run.  The plan is plain data: it can be built once while a HIP graph is
+ * captured and is not needed for replays. */
+#define UNFLOW_PLAN_CAPACITY 128
+typedef struct {
+  int n;
+  const float *partial[UNFLOW_PLAN_CAPACITY];
+  int count[UNFLOW_PLAN_CAPACITY];
+  double inv_norm[UNFLOW_PLAN_CAPACITY];
+} unflow_reduce_plan;
+int unflow_reduce_plan_begin(unflow_reduce_plan *plan);
+int unflow_reduce_plan_end(void);
+int unflow_reduce_plan_run(const unflow_reduce_plan *plan, const float *coeff, const int *term,
+                           const float *term_weight, float *results, float *total, float *per_term,
+                           unflow_stream_t stream);
+/* out[i] = sum_{k < n} srcs[k][i] for i < count: the gradient contributions of the n consumers of one tensor in ONE
+ * launch (an autograd engine issues n - 1 adds).  srcs is a HOST array of n <= 8 device pointers. */
+int unflow_sum_tensors(const float *const *srcs, int n, float *out, long long count, unflow_stream_t stream);
+
 int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped, const float *mask,
                             float *loss, float *dldd, float *dist, float *workspace, int B, int H,
                             int W, int max_distance, long long norm_count, unflow_stream_t stream);

@@ -1051,3 +1051,60 @@ def test_unaligned_tensors_take_the_same_results(dev):
     lr = torch.randn((2, 5, 16, 2), device=dev, generator=g)
     assert torch.equal(flownet.stacked_inputs(uim, _offset_by_one_float(im2), _offset_by_one_float(lr)),
                        flownet.stacked_inputs(im, im2, lr))
+
+
+def test_deferred_reductions_match_immediate(dev):
+    """unflow_reduce_plan_*: the loss forwards of a deferred block leave their partial sums behind and ONE launch
+    reduces them -- the same fixed-order double accumulation as the immediate one-block reduction, so every scalar
+    is bit-identical; the fold gives the weighted total and the per-term sums."""
+    from unflow_amd import losses
+    rng = np.random.default_rng(91)
+    B, H, W = 2, 40, 56
+    im1, im2, flow = _pair(rng, B, H, W)
+    tim1, tim2, tflow = T(im1, dev), T(im2, dev), T(flow, dev)
+    mask = (torch.rand((B, H, W, 1), device=dev) > 0.2).float()
+    dens = torch.rand((B, H, W, 1), device=dev) * 2
+
+    def run():
+        return [losses.ternary_loss(tim1, tim2, mask, 1), losses.ternary_loss(tim1, tim2, mask, 3),
+                losses.ternary_loss_warped(tim1, tim2, tflow, mask, 2), losses.charbonnier_loss(tim1 - tim2, mask, beta=255),
+                losses.smoothness_loss(tflow), losses.second_order_loss(tflow), losses.gradient_loss(tim1, tim2, mask),
+                losses.sym_loss(mask, dens), losses.occ_loss(mask),
+                losses.charbonnier_loss(torch.zeros((0, 4, 4, 2), device=dev))]          # an empty tensor: an empty segment
+    want = [float(v) for v in run()]
+    with losses.DeferredReductions(dev) as d:
+        got = run()
+        assert d.plan.n == len(want)
+    coeff = [0.5 + i for i in range(len(want))]
+    term = [i % 8 for i in range(len(want))]
+    total = torch.empty((), device=dev)
+    per_term = torch.empty(8, device=dev)
+    d.fold(coeff, term, [2.0] * len(want), total, per_term)
+    assert [float(v) for v in got] == want                      # bit-identical scalars
+    np.testing.assert_allclose(float(total), sum(c * w for c, w in zip(coeff, want)), rtol=1e-6)
+    for t in range(8):
+        np.testing.assert_allclose(float(per_term[t]), sum(2.0 * w for i, w in enumerate(want) if i % 8 == t), rtol=1e-6)
+    assert losses.DeferredReductions.active is None
+    assert float(losses.charbonnier_loss(tim1 - tim2, mask, beta=255)) == want[3]        # the immediate form is back
+    with pytest.raises(RuntimeError, match="nest"):
+        with losses.DeferredReductions(dev):
+            with losses.DeferredReductions(dev):
+                pass
+    assert losses.DeferredReductions.active is None
+
+
+def test_fan_out_sums_the_consumers_gradients_in_one_launch(dev):
+    """losses._fan_out: n aliases of a tensor whose gradients are summed by unflow_sum_tensors (same order as a chain
+    of adds); unused aliases contribute nothing."""
+    from unflow_amd import losses
+    x = torch.randn((3, 5, 7, 2), device=dev, requires_grad=True)
+    a = losses._fan_out(x, 6)
+    ws = [torch.randn_like(x) for _ in range(4)]
+    (a[0] * ws[0] + a[2] * ws[1] + a[3] * ws[2] + a[5] * ws[3]).sum().backward()
+    want = ((ws[0] + ws[1]) + ws[2]) + ws[3]
+    assert torch.equal(x.grad, want)
+    y = torch.randn((2, 3), device=dev, requires_grad=True)
+    b = losses._fan_out(y, 3)
+    (b[1] * 2.0).sum().backward()
+    assert torch.equal(y.grad, torch.full_like(y, 2.0))
+    assert losses._fan_out(y.detach(), 4)[2] is not None and losses._fan_out(y.detach(), 4)[0].data_ptr() == y.data_ptr()

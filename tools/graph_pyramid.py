@@ -28,6 +28,9 @@ def timeit(fn, n=10):
     return (time.perf_counter() - t0) / n * 1e3
 
 print("eager  %.3f ms" % timeit(step))
+_, ga = step()
+_, gb = step()
+print("eager vs eager max grad diff", max(float((a - b).abs().max()) for a, b in zip(ga, gb)), "max |grad|", max(float(a.abs().max()) for a in ga))
 s = torch.cuda.Stream()
 s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):

@@ -40,6 +40,10 @@ SIGNATURES = {
     "unflow_forward_warp_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "unflow_downsample_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "unflow_reduce_workspace_floats": (ctypes.c_size_t, [_I, _I, _I]),
+    "unflow_reduce_plan_begin": (_I, [_P]),
+    "unflow_reduce_plan_end": (_I, []),
+    "unflow_reduce_plan_run": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "unflow_sum_tensors": (_I, [_P, _I, _P, _LL, _P]),
     "unflow_ternary_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),
     "unflow_ternary_loss_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "unflow_ternary_loss_warp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),
@@ -74,6 +78,15 @@ SIGNATURES = {
     "unflow_resize_bilinear_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "unflow_resize_area_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
+
+PLAN_CAPACITY = 128   # UNFLOW_PLAN_CAPACITY
+
+
+class ReducePlan(ctypes.Structure):
+    """unflow_reduce_plan of include/unflow_hip.h: caller-owned list of deferred loss reductions."""
+    _fields_ = [("n", _I), ("partial", _P * PLAN_CAPACITY), ("count", _I * PLAN_CAPACITY),
+                ("inv_norm", ctypes.c_double * PLAN_CAPACITY)]
+
 
 _lib = None
 

@@ -816,10 +816,80 @@ inline long long tile_blocks(int B, int H, int W) {
 
 }  // namespace
 
+// the plan of this thread between unflow_reduce_plan_begin() and _end(): caller-owned, plain data
+static thread_local unflow_reduce_plan *t_plan = nullptr;
+
 int reduce_partials(const float *partial, int n, double inv_norm, float *loss, hipStream_t s) {
+  if (t_plan) {                      // deferred: the caller reduces every segment of the plan in one launch later
+    if (t_plan->n >= UNFLOW_PLAN_CAPACITY)
+      return fail(UNFLOW_ERR_INVALID_ARGUMENT, "reduce plan: more than %d deferred reductions", UNFLOW_PLAN_CAPACITY);
+    const int i = t_plan->n++;
+    t_plan->partial[i] = partial;
+    t_plan->count[i] = n;
+    t_plan->inv_norm[i] = inv_norm;
+    return UNFLOW_OK;
+  }
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, partial, n, inv_norm, loss);
   return launch_status("reduce_partials");
 }
+
+int zero_loss(float *loss, const char *what, hipStream_t s) {
+  if (t_plan) return reduce_partials(nullptr, 0, 0.0, loss, s);
+  if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status(what);
+  return UNFLOW_OK;
+}
+
+namespace {
+struct PlanArgs {
+  const float *partial[UNFLOW_PLAN_CAPACITY];
+  double inv_norm[UNFLOW_PLAN_CAPACITY];
+  int count[UNFLOW_PLAN_CAPACITY];
+};
+struct FoldArgs {
+  float coeff[UNFLOW_PLAN_CAPACITY], term_weight[UNFLOW_PLAN_CAPACITY];
+  int term[UNFLOW_PLAN_CAPACITY];
+};
+// one block per segment: the arithmetic of reduce_partials_kernel (fixed order, double accumulation)
+__global__ __launch_bounds__(1024) void reduce_segments_kernel(PlanArgs a, float *__restrict__ results) {
+  __shared__ double sh[1024];
+  const float *partial = a.partial[blockIdx.x];
+  const int n = a.count[blockIdx.x];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) results[blockIdx.x] = (float)(sh[0] * a.inv_norm[blockIdx.x]);
+}
+// one wave: total and the per-term sums, each in the order of the plan (float, like the host-side fold it replaces)
+__global__ __launch_bounds__(64) void fold_results_kernel(FoldArgs a, int n, const float *__restrict__ results,
+                                                          float *__restrict__ total, float *__restrict__ per_term) {
+  const int t = threadIdx.x;
+  if (t == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s = fmaf(a.coeff[i], results[i], s);
+    *total = s;
+  } else if (t <= 8 && per_term) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i)
+      if (a.term[i] == t - 1) s = fmaf(a.term_weight[i], results[i], s);
+    per_term[t - 1] = s;
+  }
+}
+struct SumArgs {
+  const float *src[8];
+};
+__global__ __launch_bounds__(256) void sum_tensors_kernel(SumArgs a, int n, float *__restrict__ out, long long count) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < count; i += (long long)gridDim.x * 256) {
+    float s = a.src[0][i];
+    for (int k = 1; k < n; ++k) s += a.src[k][i];        // the order autograd's chain of adds would take
+    out[i] = s;
+  }
+}
+}  // namespace
 
 }  // namespace unflow
 
@@ -834,6 +904,57 @@ extern "C" size_t unflow_reduce_workspace_floats(int B, int H, int W) {
   return (size_t)(tiles > kReduceBlocks ? tiles : kReduceBlocks);
 }
 
+extern "C" int unflow_reduce_plan_begin(unflow_reduce_plan *plan) {
+  if (!plan) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "reduce plan: NULL plan");
+  if (t_plan) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "reduce plan: a plan is already open on this thread");
+  plan->n = 0;
+  t_plan = plan;
+  return UNFLOW_OK;
+}
+
+extern "C" int unflow_reduce_plan_end(void) {
+  t_plan = nullptr;
+  return UNFLOW_OK;
+}
+
+extern "C" int unflow_reduce_plan_run(const unflow_reduce_plan *plan, const float *coeff, const int *term,
+                                      const float *term_weight, float *results, float *total, float *per_term,
+                                      unflow_stream_t stream) {
+  if (!plan || plan->n < 0 || plan->n > UNFLOW_PLAN_CAPACITY || !coeff || !results || !total)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "reduce plan: invalid plan or NULL buffer");
+  hipStream_t s = as_stream(stream);
+  const int n = plan->n;
+  if (n > 0) {
+    PlanArgs pa;
+    for (int i = 0; i < UNFLOW_PLAN_CAPACITY; ++i) {
+      pa.partial[i] = i < n ? plan->partial[i] : nullptr;
+      pa.inv_norm[i] = i < n ? plan->inv_norm[i] : 0.0;
+      pa.count[i] = i < n ? plan->count[i] : 0;
+    }
+    hipLaunchKernelGGL(reduce_segments_kernel, dim3(n), dim3(1024), 0, s, pa, results);
+    if (int rc = launch_status("reduce_plan_run")) return rc;
+  }
+  FoldArgs fa;
+  for (int i = 0; i < UNFLOW_PLAN_CAPACITY; ++i) {
+    fa.coeff[i] = i < n ? coeff[i] : 0.f;
+    fa.term_weight[i] = (i < n && term_weight) ? term_weight[i] : 0.f;
+    fa.term[i] = (i < n && term) ? term[i] : -1;
+  }
+  hipLaunchKernelGGL(fold_results_kernel, dim3(1), dim3(64), 0, s, fa, n, results, total, per_term);
+  return launch_status("reduce_plan_run fold");
+}
+
+extern "C" int unflow_sum_tensors(const float *const *srcs, int n, float *out, long long count, unflow_stream_t stream) {
+  if (!srcs || n < 1 || n > 8 || count < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "sum_tensors: 1 <= n <= 8 sources");
+  if (count == 0) return UNFLOW_OK;
+  SumArgs a;
+  for (int k = 0; k < 8; ++k) a.src[k] = k < n ? srcs[k] : nullptr;
+  const long long blocks = (count + 255) / 256;
+  hipLaunchKernelGGL(sum_tensors_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, as_stream(stream), a, n,
+                     out, count);
+  return launch_status("sum_tensors");
+}
+
 extern "C" int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped, const float *mask, float *loss,
                                        float *dldd, float *dist, float *workspace, int B, int H, int W,
                                        int max_distance, long long norm_count, unflow_stream_t stream) {
@@ -844,8 +965,7 @@ extern "C" int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped
   const long long npix = (long long)B * H * W;
   if (npix == 0) {
     // reduce_sum of an empty tensor / 0 -> NaN in TF; keep the sum (0) and do not divide.
-    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("ternary_loss memset");
-    return UNFLOW_OK;
+    return zero_loss(loss, "ternary_loss", s);
   }
   const double norm = norm_count > 0 ? (double)norm_count : (double)npix;
   const int r = max_distance;
@@ -873,9 +993,7 @@ extern "C" int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped
   }
 #undef LAUNCH_FWD
   if (int rc = launch_status("ternary_loss_fwd")) return rc;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, workspace, (int)tile_blocks(B, H, W),
-                     1.0 / norm, loss);
-  return launch_status("ternary_loss_fwd reduce");
+  return reduce_partials(workspace, (int)tile_blocks(B, H, W), 1.0 / norm, loss, s);
 }
 
 extern "C" int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped, const float *dldd,
@@ -948,16 +1066,14 @@ extern "C" int unflow_charbonnier_fwd(const float *x, const float *mask, int mas
     return fail(UNFLOW_ERR_INVALID_ARGUMENT, "charbonnier_loss: mask channels must be 1 or match x");
   hipStream_t s = as_stream(stream);
   if (n == 0) {
-    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("charbonnier memset");
-    return UNFLOW_OK;
+    return zero_loss(loss, "charbonnier", s);
   }
   const unsigned grid = ew_grid(n);
   hipLaunchKernelGGL(charbonnier_fwd_kernel, dim3(grid), dim3(256), 0, s, x, mask, mask_channels, workspace, n, C,
                      alpha, beta, epsilon, truncate);
   if (int rc = launch_status("charbonnier_fwd")) return rc;
   const double norm = norm_count > 0 ? (double)norm_count : (double)n;
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, workspace, (int)grid, 1.0 / norm, loss);
-  return launch_status("charbonnier_fwd reduce");
+  return reduce_partials(workspace, (int)grid, 1.0 / norm, loss, s);
 }
 
 extern "C" int unflow_charbonnier_bwd(const float *x, const float *mask, int mask_channels, const float *gout,
@@ -1033,8 +1149,7 @@ extern "C" int unflow_sym_loss_fwd(const float *mask, const float *density, floa
   if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "sym_loss: negative dimension");
   hipStream_t s = as_stream(stream);
   if (n == 0) {
-    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("sym_loss memset");
-    return UNFLOW_OK;
+    return zero_loss(loss, "sym_loss", s);
   }
   const unsigned grid = ew_grid(n);
   hipLaunchKernelGGL(sym_loss_kernel, dim3(grid), dim3(256), 0, s, mask, density, thresh, workspace, n);
@@ -1055,8 +1170,7 @@ extern "C" int unflow_ternary_loss_warp_fwd(const float *im1, const float *im2, 
   hipStream_t s = as_stream(stream);
   const long long npix = (long long)B * H * W;
   if (npix == 0) {
-    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("ternary_loss_warp memset");
-    return UNFLOW_OK;
+    return zero_loss(loss, "ternary_loss_warp", s);
   }
   const double norm = norm_count > 0 ? (double)norm_count : (double)npix;
   const int r = max_distance;

@@ -30,6 +30,9 @@ inline int launch_status(const char *what) {
 // Final pass of every loss reduction (census.hip): *loss = sum(partial[0..n)) * inv_norm,
 // one block, fixed order, double accumulation.
 int reduce_partials(const float *partial, int n, double inv_norm, float *loss, hipStream_t s);
+// *loss = 0 for an empty tensor (reduce_sum of nothing; TF would go on to divide 0 by 0): an empty segment when a
+// reduce plan is open on this thread
+int zero_loss(float *loss, const char *what, hipStream_t s);
 
 inline hipStream_t as_stream(unflow_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

@@ -328,8 +328,7 @@ extern "C" int unflow_smoothness_loss_fwd(const float *flow, float *loss, float 
   hipStream_t s = as_stream(stream);
   const long long npix = (long long)B * H * W;
   if (npix == 0) {
-    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("smoothness_loss memset");
-    return UNFLOW_OK;
+    return zero_loss(loss, "smoothness_loss", s);
   }
   const int K = order == 1 ? 2 : 4;
   const double norm = norm_count > 0 ? (double)norm_count : (double)npix * K;
@@ -375,8 +374,7 @@ extern "C" int unflow_gradient_loss_fwd(const float *im1, const float *im2_warpe
   hipStream_t s = as_stream(stream);
   const long long npix = (long long)B * H * W;
   if (npix == 0) {
-    if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status("gradient_loss memset");
-    return UNFLOW_OK;
+    return zero_loss(loss, "gradient_loss", s);
   }
   const double norm = norm_count > 0 ? (double)norm_count : (double)npix * 6;
   hipLaunchKernelGGL(gradient_loss_fwd_kernel, tile_grid(B, H, W), dim3(kNT), 0, s, im1, im2_warped, mask, workspace,

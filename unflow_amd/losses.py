@@ -27,6 +27,88 @@ def _workspace(B, H, W, device):
     return torch.empty(int(n), device=device, dtype=torch.float32)
 
 
+# --------------------------------------------------------------------------- deferred reductions
+class DeferredReductions:
+    """``with DeferredReductions(device) as d:`` -- every loss forward inside leaves its per-workgroup partial
+    sums in its workspace and returns ``d.results[slot]`` (not yet written) instead of launching its own one-block
+    final reduction; ``d.fold(...)`` then reduces all of them in ONE launch and folds the weighted sum in a second.
+    The loss pyramid of the reference (core/unsupervised.py:114-141) evaluates ~40 scalars per step: ~40 launches
+    become 2.  The C side is ``unflow_reduce_plan_*`` (include/unflow_hip.h); the plan is per thread."""
+
+    active = None
+
+    def __init__(self, device):
+        self.plan = _lib.ReducePlan()
+        self.results = torch.empty(_lib.PLAN_CAPACITY, device=device, dtype=torch.float32)
+        self.keep = []              # the workspaces must live until fold()
+
+    def __enter__(self):
+        if DeferredReductions.active is not None:
+            raise RuntimeError("DeferredReductions does not nest")
+        _lib.check(_lib.load().unflow_reduce_plan_begin(ctypes.byref(self.plan)))
+        DeferredReductions.active = self
+        return self
+
+    def __exit__(self, *exc):
+        DeferredReductions.active = None
+        _lib.load().unflow_reduce_plan_end()
+        return False
+
+    def last(self, ws):
+        self.keep.append(ws)
+        return self.results[self.plan.n - 1]
+
+    def fold(self, coeff, term, term_weight, total, per_term):
+        """results[0..n) <- the deferred reductions; total <- sum coeff[i] results[i]; per_term[t] <- sum over the
+        segments of term t of term_weight[i] results[i] (host sequences of plan.n entries)."""
+        n = self.plan.n
+        c = (ctypes.c_float * max(n, 1))(*coeff)
+        t = (ctypes.c_int * max(n, 1))(*term)
+        w = (ctypes.c_float * max(n, 1))(*term_weight)
+        with torch.cuda.device(self.results.device):
+            _lib.check(_lib.load().unflow_reduce_plan_run(ctypes.byref(self.plan), c, t, w, _ptr(self.results), _ptr(total),
+                                                          _ptr(per_term), _stream()))
+
+
+def _loss_out(device):
+    """The scalar a loss forward writes -- None (NULL: not written) while reductions are deferred."""
+    return None if DeferredReductions.active is not None else torch.empty((), device=device, dtype=torch.float32)
+
+
+def _loss_result(loss, ws):
+    d = DeferredReductions.active
+    return loss if d is None else d.last(ws)
+
+
+class _FanOut(torch.autograd.Function):
+    """n aliases of one tensor, one per consumer: the backward pass then sums the consumers' gradients in ONE launch
+    (``unflow_sum_tensors``) where the autograd engine would issue n - 1 adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)      # an alias nobody used has no gradient: no zero-fill launch for it
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [g.contiguous() for g in grads if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        out = torch.empty_like(live[0])
+        ptrs = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.load().unflow_sum_tensors(ptrs, len(live), _ptr(out), out.numel(), _stream()))
+        return out, None
+
+
+def _fan_out(x, n):
+    if torch.is_grad_enabled() and x.requires_grad and x.is_cuda and x.dtype == torch.float32:
+        return _FanOut.apply(x, n)
+    return (x,) * n
+
+
 def length_sq(x):
     return torch.sum(torch.square(x), 3, keepdim=True)
 
@@ -121,12 +203,12 @@ def sym_loss(mask, density_other, norm_count=0, thresh=DISOCC_THRESH):
     B, H, W, C = mask.shape
     if C != 1 or density_other.shape != mask.shape:
         raise ValueError("sym_loss expects two [B,H,W,1] maps")
-    loss = torch.empty((), device=mask.device, dtype=torch.float32)
+    loss = _loss_out(mask.device)
     ws = _workspace(B, H, W, mask.device)
     with torch.cuda.device(mask.device):
         _lib.check(_lib.load().unflow_sym_loss_fwd(_ptr(mask), _ptr(density_other), float(thresh), _ptr(loss),
                                                    _ptr(ws), B, H, W, norm_count, _stream()))
-    return loss
+    return _loss_result(loss, ws)
 
 
 def occ_loss(mask, norm_count=0):
@@ -162,7 +244,7 @@ class _Charbonnier(torch.autograd.Function):
             mc = mask.shape[3]
             if mask.shape[:3] != x.shape[:3] or mc not in (1, C):
                 raise ValueError("mask channels must be 1 or match x")
-        loss = torch.empty((), device=x.device, dtype=torch.float32)
+        loss = _loss_out(x.device)
         ws = _workspace(B, H, W, x.device)
         with torch.cuda.device(x.device):
             _lib.check(_lib.load().unflow_charbonnier_fwd(
@@ -170,7 +252,7 @@ class _Charbonnier(torch.autograd.Function):
                 truncate or 0.0, norm_count, _stream()))
         ctx.save_for_backward(x, mask)
         ctx.cfg = (mc, truncate or 0.0, alpha, beta, epsilon, norm_count)
-        return loss
+        return _loss_result(loss, ws)
 
     @staticmethod
     def backward(ctx, gout):
@@ -230,14 +312,14 @@ class _SmoothnessLoss(torch.autograd.Function):
         _require_rank4(flow, "flow")
         _check_flow(None, flow)
         B, H, W, _ = flow.shape
-        loss = torch.empty((), device=flow.device, dtype=torch.float32)
+        loss = _loss_out(flow.device)
         ws = _workspace(B, H, W, flow.device)
         with torch.cuda.device(flow.device):
             _lib.check(_lib.load().unflow_smoothness_loss_fwd(_ptr(flow), _ptr(loss), _ptr(ws), B, H, W,
                                                               order, norm_count, _stream()))
         ctx.save_for_backward(flow)
         ctx.cfg = (order, norm_count)
-        return loss
+        return _loss_result(loss, ws)
 
     @staticmethod
     def backward(ctx, gout):
@@ -288,14 +370,14 @@ class _GradientLoss(torch.autograd.Function):
                              % (tuple(im1.shape), tuple(im2_warped.shape)))
         if tuple(mask.shape) != (B, H, W, 1):
             raise ValueError("mask must have shape %s, got %s" % ((B, H, W, 1), tuple(mask.shape)))
-        loss = torch.empty((), device=im1.device, dtype=torch.float32)
+        loss = _loss_out(im1.device)
         ws = _workspace(B, H, W, im1.device)
         with torch.cuda.device(im1.device):
             _lib.check(_lib.load().unflow_gradient_loss_fwd(_ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss),
                                                             _ptr(ws), B, H, W, norm_count, _stream()))
         ctx.save_for_backward(im1, im2_warped, mask)
         ctx.norm_count = norm_count
-        return loss
+        return _loss_result(loss, ws)
 
     @staticmethod
     def backward(ctx, gout):
@@ -328,7 +410,7 @@ class _TernaryLoss(torch.autograd.Function):
                              % (tuple(im1.shape), tuple(im2_warped.shape)))
         if tuple(mask.shape) != (B, H, W, 1):
             raise ValueError("mask must have shape %s, got %s" % ((B, H, W, 1), tuple(mask.shape)))
-        loss = torch.empty((), device=im1.device, dtype=torch.float32)
+        loss = _loss_out(im1.device)
         dldd = torch.empty((B, H, W), device=im1.device, dtype=torch.float32)
         ws = _workspace(B, H, W, im1.device)
         with torch.cuda.device(im1.device):
@@ -337,7 +419,7 @@ class _TernaryLoss(torch.autograd.Function):
                 B, H, W, max_distance, norm_count, _stream()))
         ctx.save_for_backward(im1, im2_warped, dldd)
         ctx.max_distance = max_distance
-        return loss
+        return _loss_result(loss, ws)
 
     @staticmethod
     def backward(ctx, gout):
@@ -365,7 +447,7 @@ class _TernaryWarped(torch.autograd.Function):
         B, H, W, C = im1.shape
         if C != 3 or im2.shape != im1.shape or tuple(mask.shape) != (B, H, W, 1):
             raise ValueError("ternary_loss_warped expects [B,H,W,3] images and a [B,H,W,1] mask")
-        loss = torch.empty((), device=im1.device, dtype=torch.float32)
+        loss = _loss_out(im1.device)
         dldd, gray1, gray2w = (torch.empty((B, H, W), device=im1.device, dtype=torch.float32) for _ in range(3))
         ws = _workspace(B, H, W, im1.device)
         with torch.cuda.device(im1.device):
@@ -374,7 +456,7 @@ class _TernaryWarped(torch.autograd.Function):
                 _ptr(ws), B, H, W, max_distance, norm_count, _stream()))
         ctx.save_for_backward(im2, flow_d, gray1, gray2w, dldd)
         ctx.max_distance = max_distance
-        return loss
+        return _loss_result(loss, ws)
 
     @staticmethod
     def backward(ctx, gout):
@@ -489,12 +571,15 @@ def compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occl
     npx = nb * H * W
 
     want = (lambda k: True) if terms is None else (lambda k: k in terms)
+    # one alias of each flow per consumer (image warp, the two smoothness terms, flow and image of the flow warps,
+    # the flow difference): their gradients are summed in one launch instead of five chained adds
+    fw, bw = _fan_out(flow_fw, 6), _fan_out(flow_bw, 6)
     im2_warped = im1_warped = None
     # the warped images as graph nodes, unless the census term is their only consumer: then
     # ternary_loss_warped warps inside and differentiates straight down to the flow
     if want('photo') or want('grad') or return_aux:
-        im2_warped = image_warp(im2, flow_fw)
-        im1_warped = image_warp(im1, flow_bw)
+        im2_warped = image_warp(im2, fw[0])
+        im1_warped = image_warp(im1, bw[0])
     # Intermediates are only produced when something asks for them (TF1 runs just the nodes a
     # fetched tensor needs): the splat densities for 'sym' / 'disocc' / aux, the warped flows
     # for 'fb' / aux -- otherwise the occlusion test warps the other flow on the fly.
@@ -520,8 +605,8 @@ def compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occl
 
     flow_bw_warped = flow_fw_warped = fb_occ_fw = fb_occ_bw = None
     if want('fb') or return_aux:
-        flow_bw_warped = image_warp(flow_bw, flow_fw)
-        flow_fw_warped = image_warp(flow_fw, flow_bw)
+        flow_bw_warped = image_warp(bw[4], fw[3])
+        flow_fw_warped = image_warp(fw[4], bw[3])
         diff_fw, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
         diff_bw, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
     elif mask_occlusion == 'fb':
@@ -543,18 +628,18 @@ def compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occl
         losses['grad'] = (gradient_loss(im1, im2_warped, mask_fw, norm_count=npx * 6),
                           gradient_loss(im2, im1_warped, mask_bw, norm_count=npx * 6))
     if want('smooth_1st'):
-        losses['smooth_1st'] = (smoothness_loss(flow_fw, norm_count=npx * 2),
-                                smoothness_loss(flow_bw, norm_count=npx * 2))
+        losses['smooth_1st'] = (smoothness_loss(fw[1], norm_count=npx * 2),
+                                smoothness_loss(bw[1], norm_count=npx * 2))
     if want('smooth_2nd'):
-        losses['smooth_2nd'] = (second_order_loss(flow_fw, norm_count=npx * 4),
-                                second_order_loss(flow_bw, norm_count=npx * 4))
+        losses['smooth_2nd'] = (second_order_loss(fw[2], norm_count=npx * 4),
+                                second_order_loss(bw[2], norm_count=npx * 4))
     if want('fb'):       # flow + warped other flow: the sum the occlusion kernel already wrote (same rounding)
-        losses['fb'] = (charbonnier_loss(_FlowDiff.apply(flow_fw, flow_bw_warped, diff_fw), mask_fw, norm_count=npx * 2),
-                        charbonnier_loss(_FlowDiff.apply(flow_bw, flow_fw_warped, diff_bw), mask_bw, norm_count=npx * 2))
+        losses['fb'] = (charbonnier_loss(_FlowDiff.apply(fw[5], flow_bw_warped, diff_fw), mask_fw, norm_count=npx * 2),
+                        charbonnier_loss(_FlowDiff.apply(bw[5], flow_fw_warped, diff_bw), mask_bw, norm_count=npx * 2))
     if want('ternary') and im2_warped is None:
-        losses['ternary'] = (ternary_loss_warped(im1, im2, flow_fw, mask_fw, max_distance=data_max_distance,
+        losses['ternary'] = (ternary_loss_warped(im1, im2, fw[0], mask_fw, max_distance=data_max_distance,
                                                  norm_count=npx),
-                             ternary_loss_warped(im2, im1, flow_bw, mask_bw, max_distance=data_max_distance,
+                             ternary_loss_warped(im2, im1, bw[0], mask_bw, max_distance=data_max_distance,
                                                  norm_count=npx))
     elif want('ternary'):
         losses['ternary'] = (ternary_loss(im1, im2_warped, mask_fw, max_distance=data_max_distance,

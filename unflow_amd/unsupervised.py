@@ -9,7 +9,7 @@ passes the pyramid in and adds its own regularisation loss.
 """
 import torch
 
-from .losses import compute_losses_parts
+from .losses import DeferredReductions, compute_losses_parts
 from .util import downsample
 
 # unsupervised.py:10
@@ -56,47 +56,76 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     # GPU every one of those scalar multiplies and adds is a kernel launch (about 200 of the ~400
     # launches of the KITTI pyramid), so the per-direction scalars of all levels are collected
     # and folded with ONE dot product; autograd hands every loss its upstream weight from there.
+    # The final one-block reduction of every loss is DEFERRED as well (losses.DeferredReductions): the ~40 scalars of
+    # a 5-level pyramid leave their per-workgroup partial sums behind and one launch reduces them all, a second
+    # folds the weighted sum and the per-term sums -- 2 launches instead of ~40 reductions + stack + dot + gemv.
+    # (Measured and dropped, tools/graph_pyramid.py on one box: each level on a stream of its own, forked from and
+    # joined to the caller's stream -- the captured graph then has five parallel branches.  Eager 3.5 -> 6-9 ms (the
+    # host pays for the event traffic), graph replay 1.197 -> 1.30 ms, and the replayed gradients differed from the
+    # eager ones by 2.6e-3 of their scale: the levels stay on one stream.)
     scalars, coeffs, owners = [], [], []
-    for i in range(n_levels):
-        layer_weight, patch_distance = levels[i]
-        im1_s, im2_s, mask_s = images
-        level = compute_losses_parts(im1_s, im2_s, scaled_fw[i], scaled_bw[i],
-                                     border_mask=mask_s if params.get('border_mask') else None,
-                                     mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
-                                     norm_batch=norm_batch, terms=tuple(weights))[0]
-        for name, weight in weights.items():                                   # :134-139
-            for part in level[name]:
-                scalars.append(part)
-                coeffs.append(layer_weight * weight)
-                owners.append((name, layer_weight))
-        if i + 1 < n_levels:   # the reference also shrinks after the last level; that result is unused
-            images = tuple(downsample(t, 2) for t in images)                   # :143-145
+    with DeferredReductions(im1_norm.device) as deferred:
+        for i in range(n_levels):
+            layer_weight, patch_distance = levels[i]
+            im1_s, im2_s, mask_s = images
+            level = compute_losses_parts(im1_s, im2_s, scaled_fw[i], scaled_bw[i],
+                                         border_mask=mask_s if params.get('border_mask') else None,
+                                         mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
+                                         norm_batch=norm_batch, terms=tuple(weights))[0]
+            for name, weight in weights.items():                                   # :134-139
+                for part in level[name]:
+                    scalars.append(part)
+                    coeffs.append(layer_weight * weight)
+                    owners.append((name, layer_weight))
+            if i + 1 < n_levels:   # the reference also shrinks after the last level; that result is unused
+                images = tuple(downsample(t, 2) for t in images)                   # :143-145
     if not scalars:
         zero = torch.zeros((), device=im1_norm.device)
         return zero, {name: zero for name in LOSSES}
-    stacked = torch.stack(scalars)
-    coeff_t, table_t = _fold_tables(stacked.device, tuple(coeffs), tuple(owners))
-    total = torch.dot(stacked, coeff_t)                                        # :141
+    total, sums = _Fold.apply(deferred, tuple(coeffs), tuple(owners), *scalars)    # :141
     # combined_losses[k] = sum over levels of layer_weight * loss_k (:139): logging only, no gradient
-    with torch.no_grad():
-        sums = table_t @ stacked.detach()
     per_term = {name: sums[k] for k, name in enumerate(LOSSES)}
     return total, per_term
 
 
-_FOLD_CACHE = {}
+class _Fold(torch.autograd.Function):
+    """total = sum_k coeff_k * scalar_k over the deferred loss scalars (core/unsupervised.py:134-141) and the
+    per-term sums of the summaries, by ``unflow_reduce_plan_run``; the backward hands scalar k its coeff_k."""
+
+    @staticmethod
+    def forward(ctx, deferred, coeffs, owners, *scalars):
+        n = deferred.plan.n
+        slots = [int(sc.storage_offset()) for sc in scalars]        # each scalar is deferred.results[slot]
+        coeff = [0.0] * n
+        term = [-1] * n
+        term_w = [0.0] * n
+        for slot, c, (name, layer_weight) in zip(slots, coeffs, owners):
+            coeff[slot] = float(c)
+            term[slot] = LOSSES.index(name)
+            term_w[slot] = float(layer_weight)
+        total = torch.empty((), device=deferred.results.device, dtype=torch.float32)
+        sums = torch.empty(len(LOSSES), device=total.device, dtype=torch.float32)
+        deferred.fold(coeff, term, term_w, total, sums)
+        ctx.coeff_t = _coeff_tensor(total.device, tuple(float(c) for c in coeffs))
+        ctx.mark_non_differentiable(sums)
+        return total, sums
+
+    @staticmethod
+    def backward(ctx, g_total, g_sums):
+        g = ctx.coeff_t * g_total                                    # one launch for every scalar's upstream gradient
+        return (None, None, None) + tuple(g[k] for k in range(g.shape[0]))
 
 
-def _fold_tables(device, coeffs, owners):
-    """Device copies of the folding coefficients, built once per configuration (a host-to-device copy
-    per call would be one more launch, and could not be captured into a HIP graph)."""
-    key = (str(device), coeffs, owners)
-    if key not in _FOLD_CACHE:
-        table = torch.zeros((len(LOSSES), len(coeffs)), dtype=torch.float32)
-        for j, (name, layer_weight) in enumerate(owners):
-            table[LOSSES.index(name), j] = layer_weight
-        _FOLD_CACHE[key] = (torch.tensor(coeffs, dtype=torch.float32).to(device), table.to(device))
-    return _FOLD_CACHE[key]
+_COEFF_CACHE = {}
+
+
+def _coeff_tensor(device, coeffs):
+    """Device copy of the folding coefficients, built once per configuration (a host-to-device copy per call would be
+    one more launch, and could not be captured into a HIP graph)."""
+    key = (str(device), coeffs)
+    if key not in _COEFF_CACHE:
+        _COEFF_CACHE[key] = torch.tensor(coeffs, dtype=torch.float32).to(device)
+    return _COEFF_CACHE[key]
 
 
 class _ScaleAll(torch.autograd.Function):
