@@ -84,6 +84,70 @@ int run(const char *name, float *d, double *base_ms) {
   return 0;
 }
 
+// Dependent mode, as in the backward kernel: the B operand of a group of 4 MFMAs is an LDS read issued DISTG groups
+// earlier (1 group = 4 MFMAs of this wave); the A operands are read once per 3 groups, 1 K-step (3 groups) ahead.
+template <int DISTG, int CONFLICT>
+__global__ __launch_bounds__(1024) void kdep(float *out, float seed) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < 16384; i += 1024) lds[i] = seed * 1e-3f;
+  __syncthreads();
+  typedef __attribute__((address_space(3))) const float lds_cf;
+  const unsigned base = (unsigned)(size_t)(lds_cf *)lds + (threadIdx.x >> 6) * 2048;
+  lds_cf *pb = (lds_cf *)(size_t)(base + lane * 4 * CONFLICT);
+  lds_cf *pa = (lds_cf *)(size_t)(base + lane * 4);
+  f32x4 acc[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) acc[i] = f32x4{0, 0, 0, 0};
+  constexpr int NBUF = DISTG + 1;
+  float bq[NBUF];        // ring of B operands
+  float aq[2][4];
+#pragma unroll
+  for (int i = 0; i < NBUF; ++i) bq[i] = pb[i * 64];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { aq[0][i] = pa[i * 64]; aq[1][i] = pa[i * 64 + 16]; }
+  for (int it = 0; it < ITER; it += NBUF * 2) {
+#pragma unroll
+    for (int u = 0; u < NBUF * 2; ++u) {       // unrolled so that ring indices are compile-time
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        constexpr int dummy = 0; (void)dummy;
+        const int gi = (u * 3 + g);
+        const int slot = gi % NBUF;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[g * 4 + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[u & 1][m], bq[slot], acc[g * 4 + m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bq[slot] = pb[((gi * 7) & 31) * 64 / CONFLICT];          // refill: consumed DISTG groups from now... (ring of DISTG + 1)
+        if (g == 0) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) aq[(u + 1) & 1][m] = pa[m * 64 + ((u * 5) & 15)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 1234.5f) out[0] = s;
+}
+
+template <int DISTG, int CONFLICT>
+int rundep(float *d) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const size_t smem = 100 * 1024;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kdep<DISTG, CONFLICT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL((kdep<DISTG, CONFLICT>), dim3(256), dim3(1024), smem, 0, d, 1.0f);
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL((kdep<DISTG, CONFLICT>), dim3(256), dim3(1024), smem, 0, d, 1.0f);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const int iters = (ITER + (DISTG + 1) * 2 - 1) / ((DISTG + 1) * 2) * ((DISTG + 1) * 2);
+  printf("dependent B reads, distance %d group(s) of 4 MFMAs, %d-way: %7.3f ms  %5.1f cycles per MFMA per SIMD\n", DISTG, CONFLICT, ms,
+         ms * 1e-3 * 2.4e9 / (4.0 * iters * 12));
+  return 0;
+}
+
 int main() {
   float *d; CK(hipMalloc(&d, 1024));
   double b = 0;
@@ -100,5 +164,6 @@ int main() {
   run<9, 3>("s_cmp + untaken s_cbranch", d, &b); run<9, 12>("s_cmp + untaken s_cbranch", d, &b);
   run<10, 3>("s_waitcnt lgkmcnt(2)", d, &b); run<10, 12>("s_waitcnt lgkmcnt(2)", d, &b);
   run<11, 3>("4 VALU + 3 ds_read_b32 (one unit)", d, &b); run<11, 6>("4 VALU + 3 ds_read_b32 (one unit)", d, &b);
+  rundep<1, 1>(d); rundep<1, 2>(d); rundep<2, 1>(d); rundep<2, 2>(d); rundep<3, 2>(d); rundep<5, 2>(d);
   return 0;
 }

@@ -633,9 +633,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_mfma_fwd_half_kernel(
           UNFLOW_STAMP(ch, 2);
           dma_barrier();   // (a plain __syncthreads() came out as lgkmcnt(0) alone here)
           UNFLOW_STAMP(ch, 3);
-#ifdef UNFLOW_TUNE_FWD_SKEW    // diagnostic: the SIMD partners (waves w, w + 4) leave the barrier out of phase
-          if (wave >= 4) __builtin_amdgcn_s_sleep(UNFLOW_TUNE_FWD_SKEW);
-#endif
           if (more) st.bind(in0, in1, item, (ch + 2) * KC, C, plane);
         }
       }
@@ -1506,9 +1503,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
       if (store_tile >= 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else UNFLOW_BARRIER_DMA();
       UNFLOW_STAMP(rowc, 3);
-#ifdef UNFLOW_TUNE_BWD_SKEW    // diagnostic: the SIMD partners (tile parities) leave the barrier out of phase
-      if (ph) __builtin_amdgcn_s_sleep(UNFLOW_TUNE_BWD_SKEW);
-#endif
       kstep(Int<KSTEPS - 1>{});
       // ---- a tile that ends on this row (not the last one: 4 t + 13 == w): its owners write it to ob
       // (free: its last image was stored two rows ago); the next barrier publishes it and the row after
@@ -1543,434 +1537,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float
           UNFLOW_BARRIER_LDS();
 #pragma unroll
           for (int q = 0; q < 4; ++q) store_piece(t, q);
-          if (t + 1 < ntiles) UNFLOW_BARRIER_LDS();   // ob is rewritten by the next tile
-        }
-      }
-    }
-  }
-#undef UNFLOW_DUMP_TILE2
-}
-
-// ===========================================================================
-// Backward, 16 waves per workgroup: the row sweep of corr_mfma_bwd2_kernel -- the same LDS images, DMA
-// pieces, ring of three tiles, barrier between K-steps 4 and 5, persistent workgroups -- with FOUR waves
-// per SIMD instead of two.  Cycle stamps of the second generation (profiles/r02_bwd_stamps_rotated.txt)
-// show what its last third is: the two waves of a SIMD take the matrix pipe in priority order, the first
-// one's non-MFMA stretches are covered by the second one's MFMAs, but the second then finishes the row
-// ALONE (its stretches uncovered, the first waiting at the barrier): ~3100 cycles per row that do not
-// depend on the row's MFMA count.  Here a wave holds half of the channels of its tiles (4 M-tiles: 48
-// accumulator registers, 128 VGPRs in all), so a SIMD carries both tile parities x both channel halves
-// and the wave that runs alone at the end of a row has a quarter of the row's work left, not half.
-// Costs: every B fragment is read by two waves (7 LDS reads per 12 MFMAs instead of 11 per 24).
-// ===========================================================================
-namespace b4 {
-constexpr int NT4 = 1024, NW4 = NT4 / 64;
-constexpr int MW = MTS / 2;                                  // 4 M-tiles per wave
-constexpr int A_PW = b2::A_PIECES / NW4;                     // 2 DMA pieces of the A image per wave
-constexpr int T_PW = (b2::T_PIECES + NW4 - 1) / NW4;         // 2 of the top image (wave 15: 1)
-constexpr int ST_PW = SW_OUT / 4 / NT4;                      // 2 float4 stores of a finished tile per thread
-static_assert(b2::A_PIECES % NW4 == 0 && SW_OUT % (4 * NT4) == 0, "pieces per wave");
-}  // namespace b4
-
-template <bool WRT1>
-__global__ __launch_bounds__(b4::NT4) void corr_mfma_bwd16_kernel(const float *__restrict__ topdiff,
-                                                                     const float *__restrict__ fin,
-                                                                     float *__restrict__ gout, int C, int H, int W,
-                                                                     int nbx, int nch, int nitems) {
-  using namespace b2;
-  using namespace b4;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  __builtin_assume(wave >= 0 && wave < NW4);
-  // waves w, w + 4, w + 8, w + 12 share a SIMD: the same tile column, both tile parities, both channel halves
-  const int cx = wave & 1, tx = (wave >> 1) & 1, ph = (wave >> 2) & 1, mh = wave >> 3;
-  const long long plane = (long long)H * W;
-  const int row_bytes = S * W * 4;             // one class row further down
-
-  // items of this workgroup: XCD x (blocks b = x mod 8) walks the contiguous range
-  // [x n/8, (x+1) n/8) so that its L2 sees neighbouring strips of the same pairs
-  const bool xcd_split = (nitems & 7) == 0 && (gridDim.x & 7) == 0;
-  const int it_stride = xcd_split ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  const int it_first = xcd_split ? (int)(blockIdx.x & 7) * (nitems >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int it_end = xcd_split ? ((int)(blockIdx.x & 7) + 1) * (nitems >> 3) : nitems;
-  if (it_first >= it_end) return;
-
-  const int k = lane >> 4, n = lane & 15;
-  const int oyl = n >> 2, oxl = n & 3;
-  const int b_col = S * (tx * TP + oxl) + cx;  // column of this lane's output position in the region
-  // A fragment of M-tile m, K-step q:  a_off + m*16*ACS + 8*q   (16 channels = two groups)
-  const int a_off = (mh * MW * 16 + n) * ACS + (n >> 3) + S * (tx * TP + k) + cx;
-  float *const ob = lds + 2 * STAGE2;
-  const int dump_off = ((mh * MW * 16 + 4 * k) * TP + oyl) * RW + b_col;   // + (m*16 + j) * TP * RW
-  const int st_c4 = threadIdx.x & 3, st_rr = (threadIdx.x >> 2) & 3, st_cl = threadIdx.x >> 4;   // + 64 q channels
-  const int st_voff = (int)((st_cl * plane + (long long)(S * st_rr) * W + st_c4 * 4) * 4);        // inside the channel group
-  const float inv_c = 1.f / (float)C;
-  const bool pow2_c = (C & (C - 1)) == 0;
-
-  // ---- what the DMA of one item needs.  The last row of an item fetches nothing for it any more,
-  // so its top is where the description of the NEXT item replaces this one.
-  struct Fetch {
-    __amdgpu_buffer_rsrc_t rtop, rin;
-    unsigned a_voff[A_PW];   // channel plane + column of the lane's A segment (or OOB); the row is the SGPR offset
-    int t_base[T_PW];        // byte offset of the lane's top segment at sweep row 0 (linear in w)
-    int cy, hs;
-  };
-  // lane -> (row of the top image, valid) of its top pieces: the same for every item
-  int t_orow[T_PW];
-#pragma unroll
-  for (int j = 0; j < T_PW; ++j) {
-    const int f = ((wave + NW4 * j) * 64 + lane) * 4;
-    const int orow = f / TRS, rem = f - orow * TRS;
-    const bool cell = wave + NW4 * j < T_PIECES && orow < TROWS && rem / RW < GW;   // not the zero row / column / pad
-    t_orow[j] = cell ? orow : (1 << 28);
-  }
-  // lanes that take part in A piece j: the 4 pad floats that end every 60-float channel row are never
-  // read and must not be written either -- the last one of an odd (shifted) group is the first float
-  // of the next group
-  unsigned a_lanes = 0;
-#pragma unroll
-  for (int j = 0; j < A_PW; ++j) {
-    const int g = lane * 4 + ((wave + NW4 * j) & 1) * A_PIECE_F;
-    if (lane < A_PIECE_F / 4 && g % ACS < ROWF) a_lanes |= 1u << j;
-  }
-  struct Item {
-    int bx, chg, cy;
-    long long pair;
-  };
-  auto decode = [&](int it) {
-    Item d;
-    d.bx = it % nbx;
-    it /= nbx;
-    d.chg = it % nch;
-    it /= nch;
-    d.cy = it & 1;
-    d.pair = it >> 1;
-    return d;
-  };
-  auto make_fetch = [&](const Item &d) {
-    Fetch f;
-    f.cy = d.cy;
-    f.hs = (H - d.cy + S - 1) / S;
-    const int xs0 = d.bx * RX, c0 = d.chg * CWS;
-    f.rtop = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(topdiff + d.pair * (GW * GW) * plane), (short)0,
-                                               (int)(GW * GW * plane * 4), 0x00020000);
-    f.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fin + (d.pair * C + c0) * plane), (short)0,
-                                              (int)((long long)(C - c0) * plane * 4), 0x00020000);
-#pragma unroll
-    for (int j = 0; j < A_PW; ++j) {
-      const int p = wave + NW4 * j;                 // piece: group p >> 1, half p & 1
-      const int g = lane * 4 + (p & 1) * A_PIECE_F;    // float inside the group (lanes >= 60 take no part)
-      const int r8 = g / ACS, x = g - r8 * ACS;
-      const int c = (p >> 1) * 8 + r8;
-      const int X = S * (xs0 - R) + x;
-      f.a_voff[j] = (X >= 0 && X < W) ? (unsigned)((c * plane + X) * 4) : OOB;     // outside the image: zeros
-    }
-#pragma unroll
-    for (int j = 0; j < T_PW; ++j) {
-      const int fl = ((wave + NW4 * j) * 64 + lane) * 4;     // float of the top image: [orow][dx'][col]
-      const int orow = min(fl / TRS, TROWS - 1), rem = fl % TRS;
-      const int dxp = min(rem / RW, GW - 1), col = rem % RW;
-      int dyp, Y0, Xt;
-      if (WRT1) {   // position = window position: row w, column shifted by -dx
-        dyp = orow;
-        Y0 = d.cy;
-        Xt = S * xs0 - S * (dxp - R) + col;
-      } else {      // position = output position: row oy = w - R + orow
-        dyp = 2 * R - orow;
-        Y0 = S * (orow - R) + d.cy;
-        Xt = S * xs0 + col;
-      }
-      const bool ok = Xt + 3 >= 0 && Xt < W;     // (a straddling piece only feeds masked window columns)
-      f.t_base[j] = ok ? (int)((((long long)(dyp * GW + dxp) * H + Y0) * W + Xt) * 4) : (int)0x80000000;
-    }
-    return f;
-  };
-  // one DMA piece of window row w of the item described by f into `stage`
-  auto issue_a = [&](const Fetch &f, int j, int w, float *stage) {
-    const int p = wave + NW4 * j;
-    float *dst = stage + (p >> 1) * AG + ((p >> 1) & 1) + (p & 1) * A_PIECE_F;
-    if (a_lanes & (1u << j)) dma<4>(f.rin, dst, f.a_voff[j], (S * w + f.cy) * W * 4);
-  };
-  auto issue_t = [&](const Fetch &f, int j, int w, float *stage) {
-    if (wave + NW4 * j < T_PIECES) {
-      const int oy = w - R + t_orow[j];
-      const unsigned voff = (oy >= 0 && oy < f.hs && f.t_base[j] != (int)0x80000000) ? (unsigned)(f.t_base[j] + w * row_bytes) : OOB;
-      dma<4>(f.rtop, stage + A_STAGE + (wave + NW4 * j) * 256, voff, 0);
-    }
-  };
-
-  f32x4 acc[RING][MW];
-#pragma unroll
-  for (int sl = 0; sl < RING; ++sl)
-#pragma unroll
-    for (int m = 0; m < MW; ++m) acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#define UNFLOW_DUMP_TILE2(SLOT)                                                            \
-  do {                                                                                     \
-    const int slot_ = (SLOT);                                                              \
-    _Pragma("unroll") for (int sl = 0; sl < RING; ++sl) {                                  \
-      if (sl == slot_) {                                                                   \
-        _Pragma("unroll") for (int m = 0; m < MW; ++m) {                                  \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
-            ob[dump_off + (m * 16 + j) * TP * RW] = acc[sl][m][j]; /* scaled when stored */ \
-          acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
-        }                                                                                  \
-      }                                                                                    \
-    }                                                                                      \
-  } while (0)
-
-  Item cur_item = decode(it_first);
-  Fetch fc = make_fetch(cur_item);
-  int rowc = 0;                                  // rows done by this workgroup: stage = rowc & 1
-#pragma unroll
-  for (int j = 0; j < A_PW; ++j) issue_a(fc, j, 0, lds);
-#pragma unroll
-  for (int j = 0; j < T_PW; ++j) issue_t(fc, j, 0, lds);
-
-  UNFLOW_BARRIER_DMA();          // row 0 of the first item has landed
-#ifdef UNFLOW_TUNE_STAMPS
-  int stamp_slot = -1;           // workgroups 0..3 and 128..131, waves 0 and 4 (SIMD partners), WRT1 launch, first item
-  {
-    const int bsel = (int)blockIdx.x < 4 ? (int)blockIdx.x : ((int)blockIdx.x >= 128 && (int)blockIdx.x < 132 ? (int)blockIdx.x - 124 : -1);
-    if (WRT1 && bsel >= 0 && (wave == 0 || wave == 4)) stamp_slot = bsel * 2 + (wave >> 2);
-  }
-  UNFLOW_STAMP(STAMP_ROWS, 0);
-#endif
-
-  for (int it = it_first; it < it_end; it += it_stride) {
-    const int cy = cur_item.cy, hs = fc.hs, ntiles = (hs + TP - 1) / TP;
-    const int xs0 = cur_item.bx * RX, c0 = cur_item.chg * CWS;
-    const long long pair = cur_item.pair;
-    const bool last_item = it + it_stride >= it_end;
-    // B fragment of K-step q: dx' as an LDS offset; an invalid dx' (outside the window, or -- for the
-    // gradient wrt input 1 -- a window column outside the image) points at the all-zero column
-    int b_dx[KSTEPS];
-#pragma unroll
-    for (int q = 0; q < KSTEPS; ++q) {
-      const int dxp = WRT1 ? (oxl + 2 * R - k - 4 * q) : (k - oxl + 4 * q);
-      const int Xw = S * (xs0 + tx * TP - R + 4 * q + k) + cx;   // full-resolution column of the window position
-      const bool ok = dxp >= 0 && dxp <= 2 * R && (!WRT1 || (Xw >= 0 && Xw < W));
-      b_dx[q] = (ok ? dxp : ZERO_DX) * RW + b_col + A_STAGE;
-    }
-    // state of a row: the live tile of each ring slot (tile t = 2u + ph of this wave's parity lives
-    // in slot u % 3 while 8u <= w - 4 ph + 10 <= 8u + 23) and, per lane, the LDS row of the top image
-    // that pairs (w, this lane's output row) -- the all-zero row when there is none
-    struct RowState {
-      int tile[RING], b_row[RING];
-    };
-    auto row_state = [&](int w) __attribute__((always_inline)) {
-      RowState rs;
-      const int v = w - 4 * ph + R;              // >= 0
-      const int u_hi = v >> 3, r3 = u_hi % RING;
-#pragma unroll
-      for (int sl = 0; sl < RING; ++sl) {
-        const int back = r3 - sl + (r3 < sl ? RING : 0);
-        const int u = u_hi - back;
-        const int t = 2 * u + ph;
-        rs.tile[sl] = (u >= 0 && t < ntiles) ? t : -1;
-        const int orow = 4 * rs.tile[sl] + oyl - w + R;
-        rs.b_row[sl] = ((rs.tile[sl] >= 0 && orow >= 0 && orow <= 2 * R) ? orow : ZERO_ROW) * TRS;
-      }
-      return rs;
-    };
-    // the tile image leaves through a buffer descriptor of this item's gradient planes (channel
-    // group c0 of the pair): one per-lane offset (channel, tile row, 4-column group), everything
-    // else -- the tile, the 32-channel step of the float4 index, the strip -- in the scalar offset
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-        gout + (pair * C + c0) * plane, (short)0, (int)((long long)(C - c0) * plane * 4), 0x00020000);
-    auto store_piece = [&](int t, int q) __attribute__((always_inline)) {
-      const int idx = (int)threadIdx.x + NT4 * q;
-      const int oy = 4 * t + st_rr;
-      const int x = S * xs0 + st_c4 * 4;
-      // Every lane of every wave issues the store: the row barrier counts on exactly two stores per wave
-      // behind the last DMA piece (vmcnt(2)).  A lane outside the image gets an out-of-range VECTOR offset,
-      // which the descriptor's range check drops (C % 128 == 0: every channel exists).
-      f32x4 v = *reinterpret_cast<const f32x4 *>(ob + idx * 4);
-      if (pow2_c) v *= inv_c;
-      else v /= (float)C;
-      const int soff = (int)(((long long)(NT4 / 16) * q * plane + (long long)(S * 4 * t + cy) * W + S * xs0) * 4);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (oy < hs && x < W) ? st_voff : (int)OOB, soff, 0);
-    };
-
-    RowState rs = row_state(0);
-    int store_tile = -1;         // tile whose image in ob is stored during this row      (workgroup-uniform)
-    int dumped = -1;             // tile written to ob behind the previous row's last K-step: visible after this row's barrier
-    // (row 0 of this item has landed: fetched before the loop, or during the last rows of the previous
-    // item and waited for at the last row's barrier)
-
-    // The row barrier stands between K-steps 4 and 5, not between rows (see corr_mfma_bwd2_kernel): when it
-    // opens, the MFMAs of K-step 5 are ready to issue and the first fragments of row w + 1 are read between
-    // them.  Nothing reads row w's image after K-step 4, so that buffer takes the DMA of row w + 2 from K-step 5
-    // on: piece 0 rides K-step 5 of row w, piece 1 K-step 0 of row w + 1, four K-steps ahead of the barrier
-    // that needs it.
-    static_assert(A_PW == 2 && T_PW == 2 && ST_PW == 2, "schedule: DMA piece 0 in K-step 5, piece 1 in K-step 0; stores in K-steps 3, 4");
-#if defined(UNFLOW_TUNE_NOLDS) || defined(UNFLOW_TUNE_NOLDS_A) || defined(UNFLOW_TUNE_NOLDS_B) || defined(UNFLOW_TUNE_LDS_UNUSED)
-    float abuf[2][MW] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}}, bbuf[2][RING] = {{1.f, 1.f, 1.f}, {1.f, 1.f, 1.f}};
-#else
-    float abuf[2][MW], bbuf[2][RING];            // both double buffered: the fragments of K-step q + 1 are read inside K-step q
-#endif
-    for (int w = 0; w < hs; ++w, ++rowc) {
-      UNFLOW_STAMP(rowc, 0);
-      const float *cur = lds + (rowc & 1) * STAGE2;
-      float *nxt = lds + ((rowc + 1) & 1) * STAGE2;
-      const bool more = w + 1 < hs;
-      // piece 1 of the next sweep row (the next item's row 0 behind the last row: fc was replaced
-      // in front of the previous row's barrier)
-      const bool fetch = (more || !last_item) && !UNFLOW_TUNE_NODMA2;
-      const int wn = more ? w + 1 : 0;
-      // piece 0 of the sweep row after that, into this row's buffer
-      const bool fetch5 = (w + 2 < hs || (w + 2 == hs && !last_item)) && !UNFLOW_TUNE_NODMA2;
-      const int w5 = w + 2 < hs ? w + 2 : 0;
-      RowState rn;                               // state of row w + 1, produced in K-step 4
-
-      auto read_a = [&](const float *img, auto Q, auto M) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value, m = decltype(M)::value;
-#if defined(UNFLOW_TUNE_NOLDS) || defined(UNFLOW_TUNE_NOLDS_A)        // diagnostic (wrong results): no fragment reads
-        float t_ = abuf[q & 1][m];
-        asm volatile("" : "+v"(t_));
-        abuf[q & 1][m] = t_;
-#elif defined(UNFLOW_TUNE_LDS_UNUSED)   // diagnostic: the reads are issued, the MFMAs do not depend on them
-        float t_ = abuf[q & 1][m];
-        float s_;
-        asm volatile("ds_read_b32 %0, %1" : "=v"(s_) : "v"((int)(size_t)(img + a_off + m * 16 * ACS + 4 * S * q)));
-        asm volatile("" :: "v"(s_));
-        asm volatile("" : "+v"(t_));
-        abuf[q & 1][m] = t_;
-#else
-        abuf[q & 1][m] = img[a_off + m * 16 * ACS + 4 * S * q];
-#endif
-      };
-      auto read_b = [&](const float *img, const RowState &st, auto Q, auto SL) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value, sl = decltype(SL)::value;
-#if defined(UNFLOW_TUNE_NOLDS) || defined(UNFLOW_TUNE_NOLDS_B)
-        float t_ = bbuf[q & 1][sl];
-        asm volatile("" : "+v"(t_));
-        bbuf[q & 1][sl] = t_;
-#elif defined(UNFLOW_TUNE_LDS_UNUSED)
-        float t_ = bbuf[q & 1][sl];
-        float s_;
-        asm volatile("ds_read_b32 %0, %1" : "=v"(s_) : "v"((int)(size_t)(img + st.b_row[sl] + b_dx[q])));
-        asm volatile("" :: "v"(s_));
-        asm volatile("" : "+v"(t_));
-        bbuf[q & 1][sl] = t_;
-#else
-        bbuf[q & 1][sl] = img[st.b_row[sl] + b_dx[q]];
-#endif
-      };
-      // wave-uniform (forced into scalar registers: the compiler would otherwise rebuild them from a
-      // vector compare in front of every block)
-      const bool live0 = __builtin_amdgcn_readfirstlane(rs.tile[0]) >= 0;
-      const bool live1 = __builtin_amdgcn_readfirstlane(rs.tile[1]) >= 0;
-      const bool live2 = __builtin_amdgcn_readfirstlane(rs.tile[2]) >= 0;
-      if (w == 0) {
-        // first row of an item: nothing ran ahead of it -- its first fragments (latency exposed once
-        // per item) and piece 0 of row 1
-        static_for<0, MW>([&](auto M) { read_a(cur, Int<0>{}, M); });
-        static_for<0, RING>([&](auto SL) { read_b(cur, rs, Int<0>{}, SL); });
-        if (more && !UNFLOW_TUNE_NODMA2) {
-          issue_a(fc, 0, 1, nxt);
-          issue_t(fc, 0, 1, nxt);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      UNFLOW_STAMP(rowc, 1);
-      // One K-step of a wave: 4 MFMAs per live ring slot, and between the slots the other work of the
-      // K-step -- the A fragments of the next K-step, its B fragments, one DMA piece or one tile store.
-      auto slot_mfmas = [&](auto Q, auto SL) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value, sl = decltype(SL)::value;
-        // a dead ring slot skips its MFMAs: one wave-uniform branch per 4
-        if (sl == 0 ? live0 : (sl == 1 ? live1 : live2)) {
-#pragma unroll
-          for (int m = 0; m < MW; ++m)
-            acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[q & 1][m], bbuf[q & 1][sl], acc[sl][m], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      auto kstep = [&](auto Q) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value;
-        slot_mfmas(Q, Int<0>{});
-        if constexpr (q + 1 < KSTEPS) static_for<0, MW>([&](auto M) { read_a(cur, Int<q + 1>{}, M); });
-        else if (more) static_for<0, MW>([&](auto M) { read_a(nxt, Int<0>{}, M); });   // K-step 5: the first fragments of row w + 1
-        __builtin_amdgcn_sched_barrier(0);
-        slot_mfmas(Q, Int<1>{});
-        if constexpr (q + 1 < KSTEPS) static_for<0, RING>([&](auto SL) { read_b(cur, rs, Int<q + 1>{}, SL); });
-        else if (more) static_for<0, RING>([&](auto SL) { read_b(nxt, rn, Int<0>{}, SL); });
-        __builtin_amdgcn_sched_barrier(0);
-        slot_mfmas(Q, Int<2>{});
-        if constexpr (q == 0) {                  // piece 1 of the next sweep row
-          if (fetch) {
-            issue_a(fc, 1, wn, nxt);
-            issue_t(fc, 1, wn, nxt);
-          }
-        } else if constexpr (q == KSTEPS - 1) {  // piece 0 of the one after
-          if (fetch5) {
-            issue_a(fc, 0, w5, const_cast<float *>(cur));
-            issue_t(fc, 0, w5, const_cast<float *>(cur));
-          }
-        } else if constexpr (q >= 3) {
-          // K-steps 3, 4: the pending tile store goes LAST among the vector-memory operations in front
-          // of the barrier (behind the last DMA piece), so that the barrier can wait for the DMA
-          // without the stores
-          if (store_tile >= 0) store_piece(store_tile, q - 3);
-          if constexpr (q == 4) rn = row_state(w + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      static_for<0, KSTEPS - 1>([&](auto Q) { kstep(Q); });
-      // the description of the next item replaces this one once the last DMA of this item is out
-      // (piece 1 of row hs - 1, in K-step 0 of row hs - 2): here, in front of the barrier, where
-      // a wave that is early would only wait
-      if (w + 2 == hs && !last_item) {
-        cur_item = decode(it + it_stride);
-        fc = make_fetch(cur_item);
-      }
-      // Row barrier.  vmcnt counts loads, LDS-DMA and stores together, in issue order: the two tile
-      // stores of this row are this wave's youngest operations, and waiting for their
-      // acknowledgement (microseconds under load) is not needed for anything -- only the DMA of the
-      // next row must have landed.  (Every wave issues both: each holds lanes of tile row 0.)
-      UNFLOW_STAMP(rowc, 2);
-#ifdef UNFLOW_TUNE_NOBAR        // diagnostic (wrong results): no row barrier
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-      if (store_tile >= 0) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else UNFLOW_BARRIER_DMA();
-#endif
-      UNFLOW_STAMP(rowc, 3);
-      kstep(Int<KSTEPS - 1>{});
-      // ---- a tile that ends on this row (not the last one: 4 t + 13 == w): its owners write it to ob
-      // (free: its last image was stored two rows ago); the next barrier publishes it and the row after
-      // that stores it inside its K-steps 3, 4.
-      store_tile = dumped;
-      dumped = -1;
-#ifdef UNFLOW_TUNE_NOSTORE
-      if (C < 0)                               // diagnostic: never true at run time, opaque to the compiler
-#endif
-      if (more) {
-        const int t = (w - (TP - 1 + R)) >> 2;
-        if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
-          if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
-          dumped = t;
-        }
-      }
-      rs = rn;
-#ifdef UNFLOW_TUNE_NOSTORE
-      if (C > 0) continue;
-#endif
-      if (!more) {
-        // last row: the tile published by this row's barrier is still to be stored, and every tile that
-        // is still live ends here -- (store,) barrier, dump, barrier, store, ...
-        if (store_tile >= 0) {
-#pragma unroll
-          for (int q = 0; q < ST_PW; ++q) store_piece(store_tile, q);
-          UNFLOW_BARRIER_LDS();                  // ob is rewritten below
-        }
-        const int t_first = max(0, (w - (TP - 1 + R) + 3) >> 2);     // first t with 4 t + 13 >= w
-        for (int t = t_first; t < ntiles; ++t) {
-          if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
-          UNFLOW_BARRIER_LDS();
-#pragma unroll
-          for (int q = 0; q < ST_PW; ++q) store_piece(t, q);
           if (t + 1 < ntiles) UNFLOW_BARRIER_LDS();   // ob is rewritten by the next tile
         }
       }
@@ -2097,13 +1663,6 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
     const int nitems = (int)grid.x;
     const int nwg = nitems < num_cus() ? nitems : num_cus();
     const size_t smem2 = sizeof(float) * b2::LDS_FLOATS;
-#ifdef UNFLOW_TUNE_BWD16
-    if (int rc = reserve_lds<corr_mfma_bwd16_kernel<false>>(smem2, "correlation_bwd (mfma)")) return rc;
-    if (int rc = reserve_lds<corr_mfma_bwd16_kernel<true>>(smem2, "correlation_bwd (mfma)")) return rc;
-    hipLaunchKernelGGL(corr_mfma_bwd16_kernel<false>, dim3(nwg), dim3(b4::NT4), smem2, s, topdiff, in1, g0, C, H, W, nbx, nch, nitems);
-    hipLaunchKernelGGL(corr_mfma_bwd16_kernel<true>, dim3(nwg), dim3(b4::NT4), smem2, s, topdiff, in0, g1, C, H, W, nbx, nch, nitems);
-    return launch_status("correlation_bwd (mfma)");
-#endif
     if (int rc = reserve_lds<corr_mfma_bwd2_kernel<false>>(smem2, "correlation_bwd (mfma)")) return rc;
     if (int rc = reserve_lds<corr_mfma_bwd2_kernel<true>>(smem2, "correlation_bwd (mfma)")) return rc;
     hipLaunchKernelGGL(corr_mfma_bwd2_kernel<false>, dim3(nwg), dim3(NTHREADS), smem2, s, topdiff, in1, g0, C, H, W, nbx, nch, nitems);
@@ -2162,24 +1721,6 @@ const char *tune_flags_correlation_mfma() {
 #endif
 #ifdef UNFLOW_TUNE_NOSTORE
          " UNFLOW_TUNE_NOSTORE"
-#endif
-#ifdef UNFLOW_TUNE_FWD_SKEW
-         " UNFLOW_TUNE_FWD_SKEW"
-#endif
-#ifdef UNFLOW_TUNE_BWD_SKEW
-         " UNFLOW_TUNE_BWD_SKEW"
-#endif
-#ifdef UNFLOW_TUNE_NOBAR
-         " UNFLOW_TUNE_NOBAR"
-#endif
-#if defined(UNFLOW_TUNE_NOLDS_A) || defined(UNFLOW_TUNE_NOLDS_B) || defined(UNFLOW_TUNE_LDS_UNUSED)
-         " UNFLOW_TUNE_NOLDS_x"
-#endif
-#ifdef UNFLOW_TUNE_NOLDS
-         " UNFLOW_TUNE_NOLDS"
-#endif
-#ifdef UNFLOW_TUNE_BWD16
-         " UNFLOW_TUNE_BWD16"
 #endif
 #ifdef UNFLOW_TUNE_OLD_BWD
          " UNFLOW_TUNE_OLD_BWD"
