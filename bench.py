@@ -467,13 +467,14 @@ def kitti_config_step(wl):
     def step():
         loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, KITTI)
         return (loss,) + torch.autograd.grad(loss, pf + pb)
-    eager_ms = event_time(torch, step, n=5, warm=2)
+    # (the first eager steps also fill the caching allocator with the pyramid's ~180 temporaries: 5 warm-up steps)
+    eager_ms = event_time(torch, step, n=10, warm=5)
     gs = ugraph.GraphedStep(step)
     graph_ms = event_time(torch, gs.replay, n=10, warm=2)
     return {"note": "NOT the headline: 5-level pyramid loss of the reference's [train_kitti] config "
                     "(ternary + 3*smooth_2nd + 0.2*fb + 12.4*occ, mask_occlusion=fb), fwd+bwd, batch %d" % B,
             "eager_ms": eager_ms, "graph_ms": graph_ms, "pairs_per_s_graph": B / (graph_ms * 1e-3),
-            "loss": float(step()[0])}
+            "loss": float(step()[0].detach())}
 
 
 def traffic_record():
