@@ -286,7 +286,7 @@ def test_bench_loss_leg_cfg3(oracle_mod, dev):
                                 mask_occlusion="fb", data_max_distance=3, terms=("ternary", "sym"))
     # 491 520 pixels: a threshold pixel that flips moves the scalar by 2e-6, so the scalars hold 1e-5
     np.testing.assert_allclose(float(got["ternary"].detach()), want["ternary"], rtol=1e-5)
-    np.testing.assert_allclose(float(got["sym"]), want["sym"], rtol=1e-5)
+    np.testing.assert_allclose(float(got["sym"].detach()), want["sym"], rtol=1e-5)
     got["ternary"].backward()
     gim2 = oracle_mod.ternary_loss_grad(im1, waux["im2_warped"], waux["mask_fw"], 3)
     _, want_dfw = oracle_mod.image_warp_grad(gim2, im2, f_fw, want_im=False)
