@@ -1,0 +1,101 @@
+"""Scans the device code of libunflow_hip.so (or assembly listings) for a store-data hazard of gfx950 that LLVM's hazard
+recognizer does not cover: a VALU instruction that overwrites a data register of a VMEM store of more than 64 bits within
+two instructions of the store.  Measured (tools/ubench/store_data_hazard.hip, profiles/ubench_store_data_hazard.txt):
+`buffer_store_dwordx4 v[8:11], v0, s[8:11], s6 offen ; v_mov_b32 v8, 0` stores the NEW v8 in dword 0 of lanes 12-15
+(mod 16) in 0.5 % of the stores; with an immediate soffset even one s_nop in between leaves 0.4 %; two wait states are
+clean.  The compiler emits the SGPR-soffset form without any wait state (it takes it to be safe) -- it bit two of
+round 3's experimental kernels; the shipped kernels are checked by this script (tests/test_codegen_hazards.py).
+
+usage: python tools/check_store_hazard.py [libunflow_hip.so | file.s ...]      exit code 1 = found"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+STORE = re.compile(r"^\s*((?:buffer|global|flat|scratch)_store_(?:dwordx[34]|b96|b128))\s+(.*)$")
+WINDOW = 2       # instructions after the store that must not write its data registers
+
+
+def _regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def _valu_dst(text):
+    m = re.match(r"(v_\w+)\s+([^,]+)", text)
+    if not m:
+        return set()
+    op = m.group(1)
+    if op.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_mfma", "v_smfmac")) and not op.startswith("v_cmpx"):
+        return _regs(m.group(2).strip()) if op.startswith(("v_mfma", "v_smfmac")) else set()
+    return _regs(m.group(2).strip())
+
+
+def scan(lines, name):
+    found = []
+    kern = "?"
+    code = []
+    for raw in lines:
+        t = raw.split("//")[0].rstrip()
+        m = re.match(r"^(?:[0-9a-f]+ )?<?(_Z\w+)>?:", t.strip())     # kernel label (.s) or symbol line (objdump)
+        if m:
+            kern = m.group(1)
+            continue
+        s = t.strip()
+        if not s or s.startswith((";", ".")) or s.endswith(":"):
+            continue
+        code.append((kern, s))
+    for i, (kern, s) in enumerate(code):
+        m = STORE.match(s)
+        if not m:
+            continue
+        ops = [x.strip() for x in m.group(2).split(",")]
+        data = _regs(ops[0]) if m.group(1).startswith("buffer") else (_regs(ops[1]) if len(ops) > 1 else set())
+        for n in range(1, WINDOW + 1):
+            if i + n < len(code) and _valu_dst(code[i + n][1]) & data:
+                found.append("%s [%s]: %s   -> +%d: %s" % (name, kern[:80], s, n, code[i + n][1]))
+    return found
+
+
+def device_listings(so):
+    tmp = tempfile.mkdtemp(prefix="unflow_disasm_")
+    try:
+        local = os.path.join(tmp, os.path.basename(so))
+        shutil.copy(so, local)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in sorted(os.listdir(tmp)):
+            if "amdgcn" in f:
+                out = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+                yield f, out.split("\n")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def check(paths):
+    found, n_stores = [], 0
+    for p in paths:
+        if p.endswith(".so") or p.endswith(".o") or p.endswith(".co"):
+            for name, lines in device_listings(p):
+                n_stores += sum(1 for l in lines if STORE.match(l.split("//")[0]))
+                found += scan(lines, name)
+        else:
+            lines = open(p).read().split("\n")
+            n_stores += sum(1 for l in lines if STORE.match(l))
+            found += scan(lines, os.path.basename(p))
+    return found, n_stores
+
+
+if __name__ == "__main__":
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sys.argv[1:] or [os.path.join(root, "unflow_amd", "libunflow_hip.so")]
+    found, n = check(paths)
+    for f in found:
+        print(f)
+    print("%d wide VMEM stores scanned, %d with a data register overwritten within %d instructions" % (n, len(found), WINDOW))
+    sys.exit(1 if found else 0)
