@@ -1,0 +1,149 @@
+"""Writes unflow_amd/csrc/corr_bwd4_asm.inc: the hand-written instruction blocks of corr_mfma_bwd4_kernel
+(correlation_mfma.hip) as string-literal macros.  The kernel keeps its accumulators and fragment buffers in FIXED
+vector registers that only these blocks touch (the compiler is told through the clobber lists and stays below
+them); everything else of the kernel is C++.  Run after changing the register map:  python tools/gen_corr_bwd4_asm.py"""
+import os
+
+RING, MTS = 3, 8
+ACS = 60                      # A image: floats per channel row (correlation_mfma.hip)
+AB = [136, 144]               # A fragment buffers: 8 registers each
+BB = [152, 155]               # B fragment buffers: 3 registers each
+ACC0 = 160                    # accumulators: v[160:255], tile (slot, m) at 160 + (slot * 8 + m) * 4
+FIRST, LAST = AB[0], ACC0 + RING * MTS * 4 - 1
+assert LAST == 255
+
+
+def acc(sl, m):
+    return ACC0 + (sl * MTS + m) * 4
+
+
+def lit(lines):
+    return " \\\n".join('  "%s\\n\\t"' % l for l in lines)
+
+
+def mfmas(p, sl):
+    out = []
+    for m in range(MTS):
+        a = acc(sl, m)
+        out.append("v_mfma_f32_16x16x4_f32 v[%d:%d], v%d, v%d, v[%d:%d]" % (a, a + 3, AB[p] + m, BB[p] + sl, a, a + 3))
+    return out
+
+
+def reads(n):
+    out = []
+    for m in range(MTS):
+        out.append("ds_read_b32 v%d, %%[a_rd] offset:%d+%%[ia]" % (AB[n] + m, m * 16 * ACS * 4))
+    for sl in range(RING):
+        out.append("ds_read_b32 v%d, %%[b%d] offset:%%[ib]" % (BB[n] + sl, sl))
+    return out
+
+
+AG_BYTES = 8 * ACS * 4                      # a group of 8 channel rows of the A image
+A_STEP = 4 * AG_BYTES                        # LDS distance of a wave's consecutive A pieces (pieces p, p + 8: four groups on)
+T_STEP = 8 * 256 * 4                         # ... of its consecutive top-image pieces (8 pieces of 1 KiB on)
+TV = 158                                     # scratch registers (v158, v159) for a top-image piece's offset
+
+
+def dma_a(j):
+    # one 1-KiB piece of the A image by LDS-DMA: M0 = LDS destination, row in the scalar offset (always inside the image)
+    return ["s_add_u32 m0, %%[a_m0], %d" % (j * A_STEP), "s_nop 0",
+            "buffer_load_dwordx4 %%[av%d], %%[rin], %%[asoff] offen lds" % j]
+
+
+def dma_t(j):
+    # one piece of the top image: per-lane base (out of range for cells that must be zero) + the row's byte offset
+    tv = TV + (j & 1)      # (two scratch registers in turn: the next piece's offset is not written into the register of a load just issued)
+    return ["v_add_u32 v%d, %%[twoff], %%[tb%d]" % (tv, j), "s_add_u32 m0, %%[t_m0], %d" % (j * T_STEP), "s_nop 0",
+            "buffer_load_dwordx4 v%d, %%[rtop], 0 offen lds" % tv]
+
+
+def kstep(p, dma=None):
+    """dma None: plain; 'A': K-step 0 of a row (the four A pieces and top pieces 0, 1 of the NEXT row's stage);
+    'T': K-step 1 (top pieces 2, 3).  [fetch] = 0 skips them (last row of the last item)."""
+    n = 1 - p
+    L = ["s_waitcnt lgkmcnt(0)"]
+    for sl in range(RING):
+        L += ["s_bitcmp0_b32 %%[live], %d" % sl, "s_cbranch_scc1 %df" % (sl + 1)]
+        L += mfmas(p, sl)
+        L += ["%d:" % (sl + 1)]
+        if sl == 0:
+            L += reads(n)
+        # (every group is guarded on its own and leaves EXEC complete: the MFMAs that follow need all lanes)
+        if dma == "A":
+            if sl == 0:       # lanes that take part in an A piece: the same mask for the wave's four pieces
+                L += ["s_cmp_eq_u32 %[fetch], 0", "s_cbranch_scc1 7f", "s_mov_b64 vcc, exec", "s_and_b64 exec, exec, %[amask]"] + dma_a(0) + dma_a(1) + ["s_mov_b64 exec, vcc", "7:"]
+            elif sl == 1:
+                L += ["s_cmp_eq_u32 %[fetch], 0", "s_cbranch_scc1 8f", "s_mov_b64 vcc, exec", "s_and_b64 exec, exec, %[amask]"] + dma_a(2) + dma_a(3) + ["s_mov_b64 exec, vcc", "8:"]
+            else:
+                L += ["s_cmp_eq_u32 %[fetch], 0", "s_cbranch_scc1 9f"] + dma_t(0) + dma_t(1) + ["9:"]
+        elif dma == "T":
+            if sl == 1:
+                L += ["s_cmp_eq_u32 %[fetch], 0", "s_cbranch_scc1 8f"] + dma_t(2) + ["8:"]
+            elif sl == 2:
+                L += ["s_cmp_eq_u32 %[t3], 0", "s_cbranch_scc1 9f"] + dma_t(3) + ["9:"]
+    return L
+
+
+def row_step():
+    """The sweep state one row further (see the kernel): per ring slot the row j of the tile's life (wraps 23 -> 0 into the
+    next tile of the slot: u += 3, the slot's live bit follows), the lanes' top-image row address (one image row up, or
+    23 down at the wrap, plus the change of stage) and the address the fragments are read at (the all-zero cell for lanes
+    outside the 21 rows in the three rows at either end of a tile's life)."""
+    L = ["s_add_u32 %[zero], %[zero], %[dstage]", "v_add_u32 %[aaddr], %[dstage], %[aaddr]"]
+    for sl in range(RING):
+        a, b, c, d, e, f = (10 * (sl + 1) + k for k in range(6))
+        L += ["s_add_u32 %%[j%d], %%[j%d], 1" % (sl, sl), "s_cmp_lt_u32 %%[j%d], 24" % sl, "s_cbranch_scc1 %df" % a,
+              "s_mov_b32 %%[j%d], 0" % sl, "s_add_i32 %%[u%d], %%[u%d], 3" % (sl, sl), "s_bitset0_b32 %%[live], %d" % sl,
+              "s_cmp_lt_i32 %%[u%d], %%[tmax]" % sl, "s_cbranch_scc0 %df" % b, "s_bitset1_b32 %%[live], %d" % sl, "%d:" % b,
+              "v_add_u32 %%[br%d], %%[dwrap], %%[br%d]" % (sl, sl), "s_branch %df" % c,
+              "%d:" % a, "v_add_u32 %%[br%d], %%[dstep], %%[br%d]" % (sl, sl), "%d:" % c,
+              "s_cmp_lt_u32 %%[j%d], 3" % sl, "s_cbranch_scc1 %df" % d, "s_cmp_gt_u32 %%[j%d], 20" % sl, "s_cbranch_scc1 %df" % e,
+              "v_mov_b32 %%[bu%d], %%[br%d]" % (sl, sl), "s_branch %df" % f,
+              "%d:" % d, "v_cmp_ge_u32 vcc, %%[j%d], %%[oyl]" % sl, "v_mov_b32 %%[bu%d], %%[zero]" % sl, "v_cndmask_b32 %%[bu%d], %%[bu%d], %%[br%d], vcc" % (sl, sl, sl), "s_branch %df" % f,
+              "%d:" % e, "s_sub_u32 %%[tmp], %%[j%d], 20" % sl, "v_cmp_le_u32 vcc, %[tmp], %[oyl]", "v_mov_b32 %%[bu%d], %%[zero]" % sl, "v_cndmask_b32 %%[bu%d], %%[bu%d], %%[br%d], vcc" % (sl, sl, sl),
+              "%d:" % f]
+    return L
+
+
+def dump(sl):
+    # XDL write -> LDS data read of the same register needs software wait states (the compiler inserts them for its
+    # own code; 8-pass MFMA: 11): 24 here, once per finished tile
+    L = ["s_nop 15", "s_nop 7"] * int(os.environ.get("B4_NOPS", "1"))
+    for m in (range(MTS - 1, -1, -1) if os.environ.get("B4_REV") else range(MTS)):
+        for j in range(4):
+            L.append("ds_write_b32 %%[addr], v%d offset:%d" % (acc(sl, m) + j, (m * 16 + j) * 4 * 16 * 4))
+    L.append("s_waitcnt lgkmcnt(0)")
+    for m in range(MTS):
+        for j in range(4):
+            L.append("v_mov_b32 v%d, 0" % (acc(sl, m) + j))
+    L.append("s_nop 1")
+    return L
+
+
+out = ["// GENERATED by tools/gen_corr_bwd4_asm.py -- do not edit.  Instruction blocks of corr_mfma_bwd4_kernel.",
+       "// Register map: A fragments v[%d:%d] / v[%d:%d], B fragments v[%d:%d] / v[%d:%d], accumulators v[%d:%d]." % (
+           AB[0], AB[0] + 7, AB[1], AB[1] + 7, BB[0], BB[0] + 2, BB[1], BB[1] + 2, ACC0, LAST),
+       "#define UNFLOW_BWD4_FIRST_FIXED_VGPR %d" % FIRST,
+       "#define UNFLOW_BWD4_CLOBBERS " + ", ".join('"v%d"' % r for r in range(FIRST, LAST + 1)),
+       "// one K-step: wait for its fragments, 8 MFMAs per live ring slot (parity P buffers), the next K-step's 11 fragment",
+       "// reads (other buffers) behind slot 0.  Operands: [live] s, [a_rd] [b0] [b1] [b2] v, [ia] [ib] i"]
+for p in (0, 1):
+    out.append("#define UNFLOW_BWD4_KSTEP_P%d \\\n%s" % (p, lit(kstep(p))))
+out.append("// K-step 0 of a row + the LDS-DMA of the next row's A image and top pieces 0, 1: [fetch] [a_m0] [asoff] [t_m0] [twoff] s,")
+out.append("// [amask] s (64 bit), [rin] [rtop] s (128 bit), [av0..3] [tb0] [tb1] v; clobbers vcc, m0")
+out.append("#define UNFLOW_BWD4_KSTEP0_DMA \\\n%s" % lit(kstep(0, "A")))
+out.append("// K-step 1 + top pieces 2, 3 ([t3] = 0: the wave has no fourth piece)")
+out.append("#define UNFLOW_BWD4_KSTEP1_DMA \\\n%s" % lit(kstep(1, "T")))
+out.append("// the sweep state one row further: [zero] [j0..2] [u0..2] [live] +s, [tmp] =&s, [aaddr] [br0..2] +v, [bu0..2] =v,")
+out.append("// [dstage] [dstep] [dwrap] [tmax] s, [oyl] v; clobbers vcc, scc")
+out.append("#define UNFLOW_BWD4_ROW_STEP \\\n%s" % lit(row_step()))
+out.append("// the first fragments of an item (into the parity-0 buffers)")
+out.append("#define UNFLOW_BWD4_FIRST_READS \\\n%s" % lit(reads(0)))
+out.append("// a finished tile: accumulators of ring slot S to the epilogue image ([addr] v: byte address of the lane's")
+out.append("// (channel 4k, row, column) cell; + (m*16 + j) rows of 256 bytes), then zeroed")
+for sl in range(RING):
+    out.append("#define UNFLOW_BWD4_DUMP_S%d \\\n%s" % (sl, lit(dump(sl))))
+out.append("#define UNFLOW_BWD4_ZERO \\\n%s" % lit(["v_mov_b32 v%d, 0" % r for r in range(ACC0, LAST + 1)] + ["s_nop 1"]))
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unflow_amd", "csrc", "corr_bwd4_asm.inc")
+open(path, "w").write("\n".join(out) + "\n")
+print("wrote", path)
