@@ -740,7 +740,7 @@ def main():
                        **({"step_order": step_order} if world > 1 else {}),
                        **({"rehearsal_all_ranks_on_one_gpu": True} if shared else {})},
             "roofline": {"bound": "mfma",
-                         "kernel": "correlation backward: corr_mfma_bwd2_kernel, both gradient launches of one call",
+                         "kernel": "correlation backward: corr_mfma_bwd4_kernel, both gradient launches of one call",
                          "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP32_MATRIX_PEAK_TF,
                          "frac_basis": "HIP events around the call on the launch stream, mean over the timed region "

@@ -177,7 +177,7 @@ def test_seeded_extensions(seeded, dev):
     ((2, 32, 16, 24), dict()),                                   # FlowNetC attrs
     ((1, 256, 16, 16), dict()),                                  # BASELINE cfg1 feature shape
     ((1, 7, 9, 13), dict()),                                     # ragged extents and channels
-    # C % 128 == 0 and W % 4 == 0: the persistent row-sweep backward (corr_mfma_bwd2_kernel) --
+    # C % 128 == 0 and W % 4 == 0: the persistent row-sweep backward (corr_mfma_bwd4_kernel) --
     # odd heights (the two row classes differ in length), one-row classes, strips that leave the
     # image, more tiles than the accumulator ring holds, item counts that do not divide by 8
     ((1, 128, 9, 12), dict()),

@@ -125,8 +125,26 @@ def test_matrix_kernels_keep_their_accumulators_in_registers(tmp_path):
     assert len(names) == len(scratch) >= 8, out.stderr[-1000:]
     worst = {n: s for n, s in zip(names, scratch) if s > 0}
     assert all(s <= 128 for s in worst.values()), worst
-    hot = [s for n, s in zip(names, scratch) if "fwd_half_kernelILi4ELb0" in n or "bwd2" in n]
+    hot = [s for n, s in zip(names, scratch) if "fwd_half_kernelILi4ELb0" in n or "bwd4" in n]
     assert len(hot) == 3 and max(hot) <= 64, list(zip(names, scratch))
+    # the third-generation backward keeps its accumulators in fixed registers behind clobber lists: the compiler must
+    # count them (256 VGPRs, two waves per SIMD) and keep its own values out of scratch
+    vgprs = [int(v) for v in re.findall(r" VGPRs: (\d+)", out.stderr)]
+    b4 = [(v, s) for n, v, s in zip(names, vgprs, scratch) if "bwd4" in n]
+    assert b4 == [(256, 0), (256, 0)], b4
+
+
+def test_the_instruction_blocks_are_what_the_generator_writes(tmp_path):
+    """unflow_amd/csrc/corr_bwd4_asm.inc is generated (tools/gen_corr_bwd4_asm.py) and committed: the two must agree."""
+    import shutil
+    gen = os.path.join(ROOT, "tools", "gen_corr_bwd4_asm.py")
+    inc = os.path.join(ROOT, "unflow_amd", "csrc", "corr_bwd4_asm.inc")
+    work = tmp_path / "repo"
+    (work / "tools").mkdir(parents=True)
+    (work / "unflow_amd" / "csrc").mkdir(parents=True)
+    shutil.copy(gen, work / "tools" / "gen_corr_bwd4_asm.py")
+    subprocess.run([sys.executable, str(work / "tools" / "gen_corr_bwd4_asm.py")], check=True, capture_output=True)
+    assert open(work / "unflow_amd" / "csrc" / "corr_bwd4_asm.inc").read() == open(inc).read()
 
 
 def test_the_shipped_library_is_not_a_diagnostic_build():

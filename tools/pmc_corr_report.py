@@ -32,4 +32,4 @@ MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XC
 ---- forward
 == %s
 ---- backward (mean of the two gradient launches of one call; FETCH_SIZE / WRITE_SIZE in KB)
-== %s""" % (line("forward (corr_mfma_fwd_half_kernel<4,false>)", fwd), line("backward, one gradient (corr_mfma_bwd2_kernel<WRT1>)", bwd), fwd, bwd))
+== %s""" % (line("forward (corr_mfma_fwd_half_kernel<4,false>)", fwd), line("backward, one gradient (corr_mfma_bwd4_kernel<WRT1>)", bwd), fwd, bwd))

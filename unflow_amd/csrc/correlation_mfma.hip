@@ -802,7 +802,7 @@ constexpr int RING = 3;                         // live tiles per wave
 
 
 // First-generation row sweep: kept for fp16 storage, C % 128 != 0 and rows that are not 16-byte
-// aligned (the float32 FlowNetC shape runs corr_mfma_bwd2_kernel below).
+// aligned (the float32 FlowNetC shape runs corr_mfma_bwd4_kernel below).
 template <int VA, int VT, bool WRT1, bool FULL, bool F16 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
     const std::conditional_t<F16, _Float16, float> *__restrict__ topdiff,
@@ -1098,33 +1098,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd_kernel(
 
 
 // ===========================================================================
-// Backward, second generation (f32, 16-byte aligned rows, C % 128 == 0): the same row sweep
-// as corr_mfma_bwd_kernel, rebuilt around what cycle stamps of that kernel showed
-// (tools/stamps.py, profiles/r02_bwd_stamps.txt):
-//   * the two waves that share a SIMD run the same instruction stream in lockstep behind the
-//     row barrier, so every stretch of non-MFMA instructions (fragment reads, B masks, DMA
-//     issue, the per-row scalar set-up, the epilogue) is a stretch with the matrix pipe idle:
-//     35.7 instead of 32 cycles per MFMA inside the K-steps, ~2000 cycles per row around them;
-//   * a workgroup needs 148 KB of LDS, so a CU holds one: its launch, prologue fetch and the
-//     drain of its last stores are exposed between workgroups (6 % of the kernel).
-// Hence:
-//   * MFMA-dense streams: a row runs one of seven branch-free K-step bodies (one per set of live
-//     ring slots), in which every MFMA is followed by ONE small piece of the other work, pinned
-//     with scheduling barriers -- each wave alone can then keep the pipe busy;
-//   * no B masks: the top image has an all-zero 22nd row and 22nd displacement column (the DMA
+// Backward for the float32 FlowNetC shape (16-byte aligned rows, C % 128 == 0): the row sweep of
+// corr_mfma_bwd_kernel in its third generation.  What the generations kept:
+//   * (2nd) no B masks: the top image has an all-zero 22nd row and 22nd displacement column (the DMA
 //     range check writes them) and an invalid (row, dx') simply points there;
-//   * the scalar state of a row is computed one row ahead, inside the last K-step;
-//   * finished tiles leave through ob while the next row computes (owners dump in front of the
-//     row's barrier, everybody stores inside the last K-steps of the next row);
-//   * persistent workgroups: one per CU walks its share of the (pair, row class, channel group,
+//   * (2nd) finished tiles leave through ob while the next row computes (owners dump in front of the
+//     row's barrier, everybody stores inside K-steps 3, 4 of the row after next);
+//   * (2nd) persistent workgroups: one per CU walks its share of the (pair, row class, channel group,
 //     strip) items; the first row of the next item is fetched during the last row of this one;
-//   * LDS images without the 4-way (top) and 2-way (A) bank conflicts of the first kernel:
-//     top row stride 356, A channel groups of 8 start alternately 0 / 1 floats in.
+//   * (2nd) LDS images without the 4-way (top) and 2-way (A) bank conflicts of the first kernel:
+//     top row stride 356, A channel groups of 8 start alternately 0 / 1 floats in;
+//   * (2nd) the row barrier stands between K-steps 4 and 5: when it opens, K-step 5's MFMAs are ready and the
+//     first fragments of the next row are read behind them;
+//   * (3rd) the instruction stream of a row is WRITTEN, not compiled: see corr_mfma_bwd4_kernel below.
+// The second generation itself (the same sweep as compiled C++: 1.05-1.07 ms per call against 0.99) is
+// tools/sketches/corr_bwd2_second_generation.hip.txt.
 // ===========================================================================
 namespace b2 {
 constexpr int TROWS2 = TROWS + 1;               // 22: + one all-zero row
 constexpr int TDX2 = GW + 1;                    // 22: + one all-zero displacement column
-constexpr int ZERO_ROW = TROWS, ZERO_DX = GW;   // 21
+constexpr int ZERO_ROW = TROWS;                 // 21 (the all-zero displacement column is column GW = 21 of every row)
 constexpr int TRS = TDX2 * RW + 4;              // 356 floats per top-image row: 2-way instead of 4-way conflicts
 constexpr int T_IMAGE = TROWS2 * TRS;           // 7832
 constexpr int T_PIECES = (T_IMAGE + 255) / 256; // 31 DMA pieces of 1 KiB
@@ -1144,7 +1137,7 @@ static_assert(A_PIECES % NWAVES == 0 && 4 * LDS_FLOATS <= 160 * 1024, "LDS budge
 static_assert(ACS % 32 == 28, "A image bank pattern");
 }  // namespace b2
 
-// Barriers of the second-generation kernel, written out: the compiler's own wait-count insertion
+// Barriers of the row sweep, written out: the compiler's own wait-count insertion
 // knows nothing about the LDS side of an LDS-DMA (a plain __syncthreads() came out as vmcnt(9) in
 // front of the very first row), and its fences wait for stores nobody depends on.
 //   _DMA: every LDS-DMA (and everything older) of this wave has landed, LDS traffic done
@@ -1157,409 +1150,27 @@ static_assert(ACS % 32 == 28, "A image bank pattern");
 #else
 #define UNFLOW_TUNE_NODMA2 false
 #endif
-template <bool WRT1>
-__global__ __launch_bounds__(NTHREADS, 2) void corr_mfma_bwd2_kernel(const float *__restrict__ topdiff,
-                                                                     const float *__restrict__ fin,
-                                                                     float *__restrict__ gout, int C, int H, int W,
-                                                                     int nbx, int nch, int nitems) {
-  using namespace b2;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  __builtin_assume(wave >= 0 && wave < NWAVES);
-  const int cx = wave & 1, tx = (wave >> 1) & 1, ph = wave >> 2;
-  const long long plane = (long long)H * W;
-  const int row_bytes = S * W * 4;             // one class row further down
-
-  // items of this workgroup: XCD x (blocks b = x mod 8) walks the contiguous range
-  // [x n/8, (x+1) n/8) so that its L2 sees neighbouring strips of the same pairs
-  const bool xcd_split = (nitems & 7) == 0 && (gridDim.x & 7) == 0;
-  const int it_stride = xcd_split ? (int)(gridDim.x >> 3) : (int)gridDim.x;
-  const int it_first = xcd_split ? (int)(blockIdx.x & 7) * (nitems >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-  const int it_end = xcd_split ? ((int)(blockIdx.x & 7) + 1) * (nitems >> 3) : nitems;
-  if (it_first >= it_end) return;
-
-  const int k = lane >> 4, n = lane & 15;
-  const int oyl = n >> 2, oxl = n & 3;
-  const int b_col = S * (tx * TP + oxl) + cx;  // column of this lane's output position in the region
-  // A fragment of M-tile m, K-step q:  a_off + m*16*ACS + 8*q   (16 channels = two groups)
-  const int a_off = n * ACS + (n >> 3) + S * (tx * TP + k) + cx;
-  float *const ob = lds + 2 * STAGE2;
-  const int dump_off = (4 * k * TP + oyl) * RW + b_col;   // + (m*16 + j) * TP * RW
-  const int st_c4 = threadIdx.x & 3, st_rr = (threadIdx.x >> 2) & 3, st_cl = threadIdx.x >> 4;   // + 32 q channels
-  const int st_voff = (int)((st_cl * plane + (long long)(S * st_rr) * W + st_c4 * 4) * 4);        // inside the channel group
-  const float inv_c = 1.f / (float)C;
-  const bool pow2_c = (C & (C - 1)) == 0;
-
-  // ---- what the DMA of one item needs.  The last row of an item fetches nothing for it any more,
-  // so its top is where the description of the NEXT item replaces this one.
-  struct Fetch {
-    __amdgpu_buffer_rsrc_t rtop, rin;
-    unsigned a_voff[A_PER_WAVE];   // channel plane + column of the lane's A segment (or OOB); the row is the SGPR offset
-    int t_base[T_PER_WAVE];        // byte offset of the lane's top segment at sweep row 0 (linear in w)
-    int cy, hs;
-  };
-  // lane -> (row of the top image, valid) of its top pieces: the same for every item
-  int t_orow[T_PER_WAVE];
-#pragma unroll
-  for (int j = 0; j < T_PER_WAVE; ++j) {
-    const int f = ((wave + NWAVES * j) * 64 + lane) * 4;
-    const int orow = f / TRS, rem = f - orow * TRS;
-    const bool cell = wave + NWAVES * j < T_PIECES && orow < TROWS && rem / RW < GW;   // not the zero row / column / pad
-    t_orow[j] = cell ? orow : (1 << 28);
-  }
-  // lanes that take part in A piece j: the 4 pad floats that end every 60-float channel row are never
-  // read and must not be written either -- the last one of an odd (shifted) group is the first float
-  // of the next group
-  unsigned a_lanes = 0;
-#pragma unroll
-  for (int j = 0; j < A_PER_WAVE; ++j) {
-    const int g = lane * 4 + ((wave + NWAVES * j) & 1) * A_PIECE_F;
-    if (lane < A_PIECE_F / 4 && g % ACS < ROWF) a_lanes |= 1u << j;
-  }
-  struct Item {
-    int bx, chg, cy;
-    long long pair;
-  };
-  auto decode = [&](int it) {
-    Item d;
-    d.bx = it % nbx;
-    it /= nbx;
-    d.chg = it % nch;
-    it /= nch;
-    d.cy = it & 1;
-    d.pair = it >> 1;
-    return d;
-  };
-  auto make_fetch = [&](const Item &d) {
-    Fetch f;
-    f.cy = d.cy;
-    f.hs = (H - d.cy + S - 1) / S;
-    const int xs0 = d.bx * RX, c0 = d.chg * CWS;
-    f.rtop = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(topdiff + d.pair * (GW * GW) * plane), (short)0,
-                                               (int)(GW * GW * plane * 4), 0x00020000);
-    f.rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fin + (d.pair * C + c0) * plane), (short)0,
-                                              (int)((long long)(C - c0) * plane * 4), 0x00020000);
-#pragma unroll
-    for (int j = 0; j < A_PER_WAVE; ++j) {
-      const int p = wave + NWAVES * j;                 // piece: group p >> 1, half p & 1
-      const int g = lane * 4 + (p & 1) * A_PIECE_F;    // float inside the group (lanes >= 60 take no part)
-      const int r8 = g / ACS, x = g - r8 * ACS;
-      const int c = (p >> 1) * 8 + r8;
-      const int X = S * (xs0 - R) + x;
-      f.a_voff[j] = (X >= 0 && X < W) ? (unsigned)((c * plane + X) * 4) : OOB;     // outside the image: zeros
-    }
-#pragma unroll
-    for (int j = 0; j < T_PER_WAVE; ++j) {
-      const int fl = ((wave + NWAVES * j) * 64 + lane) * 4;     // float of the top image: [orow][dx'][col]
-      const int orow = min(fl / TRS, TROWS - 1), rem = fl % TRS;
-      const int dxp = min(rem / RW, GW - 1), col = rem % RW;
-      int dyp, Y0, Xt;
-      if (WRT1) {   // position = window position: row w, column shifted by -dx
-        dyp = orow;
-        Y0 = d.cy;
-        Xt = S * xs0 - S * (dxp - R) + col;
-      } else {      // position = output position: row oy = w - R + orow
-        dyp = 2 * R - orow;
-        Y0 = S * (orow - R) + d.cy;
-        Xt = S * xs0 + col;
-      }
-      const bool ok = Xt + 3 >= 0 && Xt < W;     // (a straddling piece only feeds masked window columns)
-      f.t_base[j] = ok ? (int)((((long long)(dyp * GW + dxp) * H + Y0) * W + Xt) * 4) : (int)0x80000000;
-    }
-    return f;
-  };
-  // one DMA piece of window row w of the item described by f into `stage`
-  auto issue_a = [&](const Fetch &f, int j, int w, float *stage) {
-    const int p = wave + NWAVES * j;
-    float *dst = stage + (p >> 1) * AG + ((p >> 1) & 1) + (p & 1) * A_PIECE_F;
-    if (a_lanes & (1u << j)) dma<4>(f.rin, dst, f.a_voff[j], (S * w + f.cy) * W * 4);
-  };
-  auto issue_t = [&](const Fetch &f, int j, int w, float *stage) {
-    if (wave + NWAVES * j < T_PIECES) {
-      const int oy = w - R + t_orow[j];
-      const unsigned voff = (oy >= 0 && oy < f.hs && f.t_base[j] != (int)0x80000000) ? (unsigned)(f.t_base[j] + w * row_bytes) : OOB;
-      dma<4>(f.rtop, stage + A_STAGE + (wave + NWAVES * j) * 256, voff, 0);
-    }
-  };
-
-  f32x4 acc[RING][MTS];
-#pragma unroll
-  for (int sl = 0; sl < RING; ++sl)
-#pragma unroll
-    for (int m = 0; m < MTS; ++m) acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#define UNFLOW_DUMP_TILE2(SLOT)                                                            \
-  do {                                                                                     \
-    const int slot_ = (SLOT);                                                              \
-    _Pragma("unroll") for (int sl = 0; sl < RING; ++sl) {                                  \
-      if (sl == slot_) {                                                                   \
-        _Pragma("unroll") for (int m = 0; m < MTS; ++m) {                                  \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j)                                    \
-            ob[dump_off + (m * 16 + j) * TP * RW] = acc[sl][m][j]; /* scaled when stored */ \
-          acc[sl][m] = f32x4{0.f, 0.f, 0.f, 0.f};                                          \
-        }                                                                                  \
-      }                                                                                    \
-    }                                                                                      \
-  } while (0)
-
-  Item cur_item = decode(it_first);
-  Fetch fc = make_fetch(cur_item);
-  int rowc = 0;                                  // rows done by this workgroup: stage = rowc & 1
-#pragma unroll
-  for (int j = 0; j < A_PER_WAVE; ++j) issue_a(fc, j, 0, lds);
-#pragma unroll
-  for (int j = 0; j < T_PER_WAVE; ++j) issue_t(fc, j, 0, lds);
-
-  UNFLOW_BARRIER_DMA();          // row 0 of the first item has landed
-#ifdef UNFLOW_TUNE_STAMPS
-  int stamp_slot = -1;           // workgroups 0..3 and 128..131, waves 0 and 4 (SIMD partners), WRT1 launch, first item
-  {
-    const int bsel = (int)blockIdx.x < 4 ? (int)blockIdx.x : ((int)blockIdx.x >= 128 && (int)blockIdx.x < 132 ? (int)blockIdx.x - 124 : -1);
-    if (WRT1 && bsel >= 0 && (wave == 0 || wave == 4)) stamp_slot = bsel * 2 + (wave >> 2);
-  }
-  UNFLOW_STAMP(STAMP_ROWS, 0);
-#endif
-
-  for (int it = it_first; it < it_end; it += it_stride) {
-    const int cy = cur_item.cy, hs = fc.hs, ntiles = (hs + TP - 1) / TP;
-    const int xs0 = cur_item.bx * RX, c0 = cur_item.chg * CWS;
-    const long long pair = cur_item.pair;
-    const bool last_item = it + it_stride >= it_end;
-    // B fragment of K-step q: dx' as an LDS offset; an invalid dx' (outside the window, or -- for the
-    // gradient wrt input 1 -- a window column outside the image) points at the all-zero column
-    int b_dx[KSTEPS];
-#pragma unroll
-    for (int q = 0; q < KSTEPS; ++q) {
-      const int dxp = WRT1 ? (oxl + 2 * R - k - 4 * q) : (k - oxl + 4 * q);
-      const int Xw = S * (xs0 + tx * TP - R + 4 * q + k) + cx;   // full-resolution column of the window position
-      const bool ok = dxp >= 0 && dxp <= 2 * R && (!WRT1 || (Xw >= 0 && Xw < W));
-      b_dx[q] = (ok ? dxp : ZERO_DX) * RW + b_col + A_STAGE;
-    }
-    // state of a row: the live tile of each ring slot (tile t = 2u + ph of this wave's parity lives
-    // in slot u % 3 while 8u <= w - 4 ph + 10 <= 8u + 23) and, per lane, the LDS row of the top image
-    // that pairs (w, this lane's output row) -- the all-zero row when there is none
-    struct RowState {
-      int tile[RING], b_row[RING];
-    };
-    auto row_state = [&](int w) __attribute__((always_inline)) {
-      RowState rs;
-      const int v = w - 4 * ph + R;              // >= 0
-      const int u_hi = v >> 3, r3 = u_hi % RING;
-#pragma unroll
-      for (int sl = 0; sl < RING; ++sl) {
-        const int back = r3 - sl + (r3 < sl ? RING : 0);
-        const int u = u_hi - back;
-        const int t = 2 * u + ph;
-        rs.tile[sl] = (u >= 0 && t < ntiles) ? t : -1;
-        const int orow = 4 * rs.tile[sl] + oyl - w + R;
-        rs.b_row[sl] = ((rs.tile[sl] >= 0 && orow >= 0 && orow <= 2 * R) ? orow : ZERO_ROW) * TRS;
-      }
-      return rs;
-    };
-    // the tile image leaves through a buffer descriptor of this item's gradient planes (channel
-    // group c0 of the pair): one per-lane offset (channel, tile row, 4-column group), everything
-    // else -- the tile, the 32-channel step of the float4 index, the strip -- in the scalar offset
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-        gout + (pair * C + c0) * plane, (short)0, (int)((long long)(C - c0) * plane * 4), 0x00020000);
-    auto store_piece = [&](int t, int q) __attribute__((always_inline)) {
-      const int idx = (int)threadIdx.x + NTHREADS * q;
-      const int oy = 4 * t + st_rr;
-      const int x = S * xs0 + st_c4 * 4;
-      // Every lane of every wave issues the store: the row barrier counts on exactly four stores per wave
-      // behind the last DMA piece (vmcnt(4)).  A lane outside the image gets an out-of-range VECTOR offset,
-      // which the descriptor's range check drops (C % 128 == 0: every channel exists).
-      f32x4 v = *reinterpret_cast<const f32x4 *>(ob + idx * 4);
-      if (pow2_c) v *= inv_c;
-      else v /= (float)C;
-      const int soff = (int)(((long long)(NTHREADS / 16) * q * plane + (long long)(S * 4 * t + cy) * W + S * xs0) * 4);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rout, (oy < hs && x < W) ? st_voff : (int)OOB, soff, 0);
-    };
-
-    RowState rs = row_state(0);
-    int store_tile = -1;         // tile whose image in ob is stored during this row      (workgroup-uniform)
-    int dumped = -1;             // tile written to ob behind the previous row's last K-step: visible after this row's barrier
-    // (row 0 of this item has landed: fetched before the loop, or during the last rows of the previous
-    // item and waited for at the last row's barrier)
-
-    // The row barrier stands between K-steps 4 and 5, not between rows: when it opens, the 12 MFMAs of
-    // K-step 5 are ready to issue (operands in registers) and the first fragments of row w + 1 -- whose
-    // image the barrier has just declared complete -- are read behind them, so neither the barrier
-    // round trip nor the LDS latency of the first fragments meets an empty matrix pipe.  Nothing reads
-    // row w's image after K-step 4's chunks, so that buffer takes the DMA of row w + 2 from K-step 5 on:
-    // piece 0 rides K-step 5 of row w, pieces 1..3 K-steps 0..2 of row w + 1, two K-steps ahead of the
-    // barrier that needs them, as before.
-    static_assert(A_PER_WAVE == 4 && T_PER_WAVE == 4, "DMA schedule: piece 0 in K-step 5, pieces 1..3 in K-steps 0..2");
-    float abuf[MTS], bbuf[2][RING];
-    for (int w = 0; w < hs; ++w, ++rowc) {
-      UNFLOW_STAMP(rowc, 0);
-      const float *cur = lds + (rowc & 1) * STAGE2;
-      float *nxt = lds + ((rowc + 1) & 1) * STAGE2;
-      const bool more = w + 1 < hs;
-      // pieces 1..3 of the next sweep row (the next item's row 0 behind the last row: fc was replaced
-      // in front of the previous row's barrier)
-      const bool fetch = (more || !last_item) && !UNFLOW_TUNE_NODMA2;
-      const int wn = more ? w + 1 : 0;
-      // piece 0 of the sweep row after that, into this row's buffer
-      const bool fetch5 = (w + 2 < hs || (w + 2 == hs && !last_item)) && !UNFLOW_TUNE_NODMA2;
-      const int w5 = w + 2 < hs ? w + 2 : 0;
-      RowState rn;                               // state of row w + 1, produced in K-step 4
-
-      auto read_a = [&](const float *img, auto Q, auto M) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value, m = decltype(M)::value;
-        abuf[m] = img[a_off + m * 16 * ACS + 4 * S * q];
-      };
-      auto read_b = [&](const float *img, const RowState &st, auto Q, auto SL) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value, sl = decltype(SL)::value;
-        bbuf[q & 1][sl] = img[st.b_row[sl] + b_dx[q]];
-      };
-      // The other work of K-step q comes in two chunks, one behind each half of the M-tiles.  The A
-      // fragments are single-buffered: M-tiles 0..3 are free once half 0 is through and are re-read
-      // (for the next K-step) right then, M-tiles 4..7 behind half 1 -- up to 12 MFMAs ahead of their use.
-      auto chunk = [&](auto Q, auto H) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value, h = decltype(H)::value;
-        if constexpr (q + 1 < KSTEPS) {
-          static_for<4 * h, 4 * h + 4>([&](auto M) { read_a(cur, Int<q + 1>{}, M); });
-          if constexpr (h == 0) static_for<0, RING>([&](auto SL) { read_b(cur, rs, Int<q + 1>{}, SL); });
-        } else if (more) {                       // K-step 5: the first fragments of row w + 1
-          static_for<4 * h, 4 * h + 4>([&](auto M) { read_a(nxt, Int<0>{}, M); });
-          if constexpr (h == 0) static_for<0, RING>([&](auto SL) { read_b(nxt, rn, Int<0>{}, SL); });
-        }
-        if constexpr (q < 3) {                   // pieces 1..3 of the next sweep row
-          if (fetch) {
-            if constexpr (h == 0) issue_a(fc, q + 1, wn, nxt);
-            else issue_t(fc, q + 1, wn, nxt);
-          }
-        } else if constexpr (q == KSTEPS - 1) {  // piece 0 of the one after
-          if (fetch5) {
-            if constexpr (h == 0) issue_a(fc, 0, w5, const_cast<float *>(cur));
-            else issue_t(fc, 0, w5, const_cast<float *>(cur));
-          }
-        } else if constexpr (h == 1) {
-          // K-steps 3, 4: the pending tile store goes LAST among the vector-memory operations in front
-          // of the barrier (behind the last DMA piece), so that the barrier can wait for the DMA
-          // without the stores
-          if (store_tile >= 0) {
-            store_piece(store_tile, 2 * (q - 3));
-            store_piece(store_tile, 2 * (q - 3) + 1);
-          }
-          if constexpr (q == 4) rn = row_state(w + 1);
-        }
-      };
-      // wave-uniform (forced into scalar registers: the compiler would otherwise rebuild them from a
-      // vector compare in front of every block)
-      const bool live0 = __builtin_amdgcn_readfirstlane(rs.tile[0]) >= 0;
-      const bool live1 = __builtin_amdgcn_readfirstlane(rs.tile[1]) >= 0;
-      const bool live2 = __builtin_amdgcn_readfirstlane(rs.tile[2]) >= 0;
-      if (w == 0) {
-        // first row of an item: nothing ran ahead of it -- its first fragments (latency exposed once
-        // per item) and piece 0 of row 1
-        static_for<0, MTS>([&](auto M) { read_a(cur, Int<0>{}, M); });
-        static_for<0, RING>([&](auto SL) { read_b(cur, rs, Int<0>{}, SL); });
-        if (more && !UNFLOW_TUNE_NODMA2) {
-          issue_a(fc, 0, 1, nxt);
-          issue_t(fc, 0, 1, nxt);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      UNFLOW_STAMP(rowc, 1);
-      auto kstep = [&](auto Q) __attribute__((always_inline)) {
-        constexpr int q = decltype(Q)::value;
-        static_for<0, 2>([&](auto H) {
-          constexpr int m0 = decltype(H)::value * (MTS / 2);
-          static_for<0, RING>([&](auto SL) {
-            constexpr int sl = decltype(SL)::value;
-            // a dead ring slot skips its MFMAs: one wave-uniform branch per 4
-            if (sl == 0 ? live0 : (sl == 1 ? live1 : live2)) {
-#ifdef UNFLOW_TUNE_NOMFMA      // diagnostic (wrong results): everything but the matrix instructions
-              {
-                const float a0_ = abuf[m0], a1_ = abuf[m0 + 1], a2_ = abuf[m0 + 2], a3_ = abuf[m0 + 3], b_ = bbuf[q & 1][sl];
-                asm volatile("" :: "v"(a0_), "v"(a1_), "v"(a2_), "v"(a3_), "v"(b_));
-              }
-#else
-#pragma unroll
-              for (int m = m0; m < m0 + MTS / 2; ++m)
-                acc[sl][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(abuf[m], bbuf[q & 1][sl], acc[sl][m], 0, 0, 0);
-#endif
-            }
-          });
-          __builtin_amdgcn_sched_barrier(0);
-          chunk(Q, H);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      };
-      static_for<0, KSTEPS - 1>([&](auto Q) { kstep(Q); });
-      // the description of the next item replaces this one once the last DMA of this item is out
-      // (pieces 1..3 of row hs - 1, in K-steps 0..2 of row hs - 2): here, in front of the barrier, where
-      // a wave that is early would only wait
-      if (w + 2 == hs && !last_item) {
-        cur_item = decode(it + it_stride);
-        fc = make_fetch(cur_item);
-      }
-      // Row barrier.  vmcnt counts loads, LDS-DMA and stores together, in issue order: the four tile
-      // stores of this row are this wave's youngest operations, and waiting for their
-      // acknowledgement (microseconds under load) is not needed for anything -- only the DMA of the
-      // next row must have landed.  (Every wave issues all four: each holds lanes of tile row 0.)
-      UNFLOW_STAMP(rowc, 2);
-      if (store_tile >= 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else UNFLOW_BARRIER_DMA();
-      UNFLOW_STAMP(rowc, 3);
-      kstep(Int<KSTEPS - 1>{});
-      // ---- a tile that ends on this row (not the last one: 4 t + 13 == w): its owners write it to ob
-      // (free: its last image was stored two rows ago); the next barrier publishes it and the row after
-      // that stores it inside its K-steps 3, 4.
-      store_tile = dumped;
-      dumped = -1;
-#ifdef UNFLOW_TUNE_NOSTORE
-      if (C < 0)                               // diagnostic: never true at run time, opaque to the compiler
-#endif
-      if (more) {
-        const int t = (w - (TP - 1 + R)) >> 2;
-        if (w >= TP - 1 + R && ((w - (TP - 1 + R)) & 3) == 0 && t < ntiles) {
-          if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
-          dumped = t;
-        }
-      }
-      rs = rn;
-#ifdef UNFLOW_TUNE_NOSTORE
-      if (C > 0) continue;
-#endif
-      if (!more) {
-        // last row: the tile published by this row's barrier is still to be stored, and every tile that
-        // is still live ends here -- (store,) barrier, dump, barrier, store, ...
-        if (store_tile >= 0) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) store_piece(store_tile, q);
-          UNFLOW_BARRIER_LDS();                  // ob is rewritten below
-        }
-        const int t_first = max(0, (w - (TP - 1 + R) + 3) >> 2);     // first t with 4 t + 13 >= w
-        for (int t = t_first; t < ntiles; ++t) {
-          if ((t & 1) == ph) UNFLOW_DUMP_TILE2((t >> 1) % RING);
-          UNFLOW_BARRIER_LDS();
-#pragma unroll
-          for (int q = 0; q < 4; ++q) store_piece(t, q);
-          if (t + 1 < ntiles) UNFLOW_BARRIER_LDS();   // ob is rewritten by the next tile
-        }
-      }
-    }
-  }
-#undef UNFLOW_DUMP_TILE2
-}
 
 // ===========================================================================
-// Backward, third generation: the second generation's row sweep with its matrix work written as INSTRUCTION
-// BLOCKS (corr_bwd4_asm.inc, generated by tools/gen_corr_bwd4_asm.py).  Measurements of round 3
+// Third generation: the row sweep with its hot instruction stream written as INSTRUCTION BLOCKS
+// (corr_bwd4_asm.inc, generated by tools/gen_corr_bwd4_asm.py).  Measurements of round 3
 // (profiles/r03_variants.txt, profiles/ubench_mfma_lds.txt): every non-MFMA instruction of a wave costs its SIMD
-// 2-3 cycles of matrix time, and the compiled K-step of corr_mfma_bwd2_kernel carries 2.4 scalar + 0.95 vector
-// instructions per MFMA (branches per 4 MFMAs, wait counts per fragment, address arithmetic, SGPR spills through
-// v_readlane) -- ~7 cycles per 32-cycle MFMA, which is its 0.66 of the peak.  Here a K-step is
-//     s_waitcnt; 3 x (s_bitcmp0, s_cbranch, 8 MFMAs); 11 ds_read_b32 with instruction offsets
-// = 7 scalar + 11 LDS instructions per 24 MFMAs, no vector ALU instruction at all.  The accumulators (96) and the
-// double-buffered fragments (22) live in FIXED registers v[136:255] that only the blocks touch: the blocks name
-// them in their clobber lists, so the compiler keeps out of them and counts them in the kernel's register
-// budget, and what the blocks leave there stays until the next block (the C++ between them needs ~75 registers
-// and allocates from v0 up; build() checks the generated code for strays).  Everything else -- items, DMA, tile
-// stores, barriers -- is the second generation's C++, unchanged.
+// 2-3 cycles of matrix time, and the compiled second generation carried 2.4 scalar + 0.95 vector instructions per
+// MFMA (a branch per 4 MFMAs, a wait count per fragment group, address arithmetic per K-step, 11-18 scalar
+// instructions per DMA issue, a per-row recomputation of the sweep state with three quarter-rate multiplies, SGPR
+// spills through v_readlane) -- ~7 cycles per 32-cycle MFMA, which was its 0.66 of the peak.  Here
+//   * a K-step is  s_waitcnt; 3 x (s_bitcmp0, s_cbranch, 8 MFMAs); 11 ds_read_b32 with instruction offsets
+//     = 7 scalar + 11 LDS instructions per 24 MFMAs, no vector ALU instruction at all;
+//   * the whole of sweep row w + 1 is fetched by 8 LDS-DMA instructions between the MFMA groups of K-steps 0, 1 of
+//     row w (M0 from one scalar add each, the row in the scalar offset / one v_add, one EXEC mask for the A pieces);
+//   * the sweep state (per ring slot: row of the tile's life, tile, live bit, the lanes' fragment addresses) moves
+//     one row further in ~27 scalar + 7 vector instructions (UNFLOW_BWD4_ROW_STEP);
+// 1.15 scalar + 0.55 vector instructions per MFMA in all (PMC), 0.99 ms per call = 0.71 of the peak, results
+// bit-equal to the second generation's.  The accumulators (96) and the double-buffered fragments (22 + 2 scratch)
+// live in FIXED registers v[136:255] that only the blocks touch: the blocks name them in their clobber lists, so
+// the compiler counts them in the kernel's register budget, and amdgpu_num_vgpr(136) ends its own allocation
+// below them (it needs ~72), so what a block leaves there is still there for the next one.  What stays C++:
+// items, the tile stores (inside the blocks they measured 0.5 % slower), the dump decisions, barriers.
 // ===========================================================================
 typedef __attribute__((address_space(3))) const float lds_cf;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1827,8 +1438,6 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
     static_assert(A_PER_WAVE == 4 && T_PER_WAVE == 4, "DMA schedule: piece 0 in K-step 5, pieces 1..3 in K-steps 0..2");
     for (int w = 0; w < hs; ++w, ++rowc) {
       UNFLOW_STAMP(rowc, 0);
-      const float *cur = lds + (rowc & 1) * STAGE2;
-      float *nxt = lds + ((rowc + 1) & 1) * STAGE2;
       const bool more = w + 1 < hs;
       // The whole of sweep row w + 1 is fetched during K-steps 0 and 1 of row w, into the other stage (free since row
       // w - 1's barrier), three K-steps ahead of the barrier that needs it.  Behind the last row of an item that is
@@ -1837,7 +1446,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         cur_item = decode(it + it_stride);
         fc = make_fetch(cur_item);
       }
-      const unsigned fetch = (more || !last_item) ? 1u : 0u;
+      const unsigned fetch = ((more || !last_item) && !UNFLOW_TUNE_NODMA2) ? 1u : 0u;
       const int wn = more ? w + 1 : 0;
       const unsigned live = (unsigned)__builtin_amdgcn_readfirstlane((int)sw_live);   // of THIS row: the state moves on behind the barrier
 
@@ -1891,7 +1500,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
                          [fetch] "s"(fetch_), [amask] "s"(amask), [a_m0] "s"(a_m0), [asoff] "s"(asoff), [rin] "s"(rin),
                          [av0] "v"(av0), [av1] "v"(av1), [av2] "v"(av2), [av3] "v"(av3),
                          [t_m0] "s"(t_m0), [twoff] "s"(twoff), [rtop] "s"(rtop), [tb0] "v"(tb0), [tb1] "v"(tb1)
-                     : "memory", "scc", "vcc", "m0", UNFLOW_BWD4_CLOBBERS);
+                     : "memory", "scc", "vcc", UNFLOW_BWD4_CLOBBERS);   // (and m0, which the compiler sets anew in front of every use of its own)
       };
       auto kstep_dma1 = [&]() __attribute__((always_inline)) {
         constexpr int ia = 4 * S * 2 * 4;
@@ -1911,7 +1520,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         asm volatile(UNFLOW_BWD4_KSTEP1_DMA
                      : : [live] "s"(live_), [a_rd] "v"(a_rd), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [ia] "i"(ia), [ib] "i"(ib),
                          [fetch] "s"(fetch_), [t3] "s"(t3), [t_m0] "s"(t_m0), [twoff] "s"(twoff), [rtop] "s"(rtop), [tb2] "v"(tb2), [tb3] "v"(tb3)
-                     : "memory", "scc", "m0", UNFLOW_BWD4_CLOBBERS);
+                     : "memory", "scc", UNFLOW_BWD4_CLOBBERS);
       };
       // K-steps 3, 4: the pending tile store goes LAST among the vector-memory operations in front of the barrier
       // (behind the DMA), so that the barrier can wait for the DMA without the stores
@@ -2128,21 +1737,14 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
 #else
   if (wide && full && H >= 4) {   // (its DMA runs two class rows ahead: a row class has >= 2 rows)
 #endif
-    // second-generation kernel: persistent workgroups, one per CU, walking the items
+    // third-generation kernel: persistent workgroups, one per CU, walking the items
     const int nitems = (int)grid.x;
     const int nwg = nitems < num_cus() ? nitems : num_cus();
     const size_t smem2 = sizeof(float) * b2::LDS_FLOATS;
-#ifndef UNFLOW_TUNE_BWD2
     if (int rc = reserve_lds<corr_mfma_bwd4_kernel<false>>(smem2, "correlation_bwd (mfma)")) return rc;
     if (int rc = reserve_lds<corr_mfma_bwd4_kernel<true>>(smem2, "correlation_bwd (mfma)")) return rc;
     hipLaunchKernelGGL(corr_mfma_bwd4_kernel<false>, dim3(nwg), dim3(NTHREADS), smem2, s, topdiff, in1, g0, C, H, W, nbx, nch, nitems);
     hipLaunchKernelGGL(corr_mfma_bwd4_kernel<true>, dim3(nwg), dim3(NTHREADS), smem2, s, topdiff, in0, g1, C, H, W, nbx, nch, nitems);
-    return launch_status("correlation_bwd (mfma)");
-#endif
-    if (int rc = reserve_lds<corr_mfma_bwd2_kernel<false>>(smem2, "correlation_bwd (mfma)")) return rc;
-    if (int rc = reserve_lds<corr_mfma_bwd2_kernel<true>>(smem2, "correlation_bwd (mfma)")) return rc;
-    hipLaunchKernelGGL(corr_mfma_bwd2_kernel<false>, dim3(nwg), dim3(NTHREADS), smem2, s, topdiff, in1, g0, C, H, W, nbx, nch, nitems);
-    hipLaunchKernelGGL(corr_mfma_bwd2_kernel<true>, dim3(nwg), dim3(NTHREADS), smem2, s, topdiff, in0, g1, C, H, W, nbx, nch, nitems);
     return launch_status("correlation_bwd (mfma)");
   }
   if (wide && full) UNFLOW_LAUNCH(4, 4, true);
@@ -2192,14 +1794,8 @@ const char *tune_flags_correlation_mfma() {
 #ifdef UNFLOW_TUNE_NODMA
          " UNFLOW_TUNE_NODMA"
 #endif
-#ifdef UNFLOW_TUNE_NOMFMA
-         " UNFLOW_TUNE_NOMFMA"
-#endif
 #ifdef UNFLOW_TUNE_NOSTORE
          " UNFLOW_TUNE_NOSTORE"
-#endif
-#ifdef UNFLOW_TUNE_BWD2
-         " UNFLOW_TUNE_BWD2"
 #endif
 #ifdef UNFLOW_TUNE_OLD_BWD
          " UNFLOW_TUNE_OLD_BWD"
