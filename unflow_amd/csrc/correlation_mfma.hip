@@ -1428,14 +1428,12 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
     // (row 0 of this item has landed: fetched before the loop, or during the last rows of the previous
     // item and waited for at the last row's barrier)
 
-    // The row barrier stands between K-steps 4 and 5, not between rows: when it opens, the 12 MFMAs of
-    // K-step 5 are ready to issue (operands in registers) and the first fragments of row w + 1 -- whose
-    // image the barrier has just declared complete -- are read behind them, so neither the barrier
-    // round trip nor the LDS latency of the first fragments meets an empty matrix pipe.  Nothing reads
-    // row w's image after K-step 4's chunks, so that buffer takes the DMA of row w + 2 from K-step 5 on:
-    // piece 0 rides K-step 5 of row w, pieces 1..3 K-steps 0..2 of row w + 1, two K-steps ahead of the
-    // barrier that needs them, as before.
-    static_assert(A_PER_WAVE == 4 && T_PER_WAVE == 4, "DMA schedule: piece 0 in K-step 5, pieces 1..3 in K-steps 0..2");
+    // The row barrier stands between K-steps 4 and 5, not between rows: when it opens, the MFMAs of K-step 5 are
+    // ready to issue (operands in registers) and the first fragments of row w + 1 -- whose image the barrier has
+    // just declared complete -- are read behind its first MFMA group, so neither the barrier round trip nor the LDS
+    // latency of the first fragments meets an empty matrix pipe.  Nothing reads row w's image after K-step 4, so
+    // that stage takes the DMA of row w + 2 during K-steps 0, 1 of row w + 1.
+    static_assert(A_PER_WAVE == 4 && T_PER_WAVE == 4, "DMA schedule of the blocks: four A and four top pieces per wave and row");
     for (int w = 0; w < hs; ++w, ++rowc) {
       UNFLOW_STAMP(rowc, 0);
       const bool more = w + 1 < hs;
