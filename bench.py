@@ -488,7 +488,8 @@ def traffic_record():
         return None, None
     with open(path) as fh:
         rec = json.load(fh)
-    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    inc = os.path.join(os.path.dirname(src), "corr_bwd4_asm.inc")      # the backward's instruction blocks are kernel source too
+    sha = hashlib.sha256(open(src, "rb").read() + (open(inc, "rb").read() if os.path.exists(inc) else b"")).hexdigest()[:16]
     if rec.get("kernel_source_sha16") != sha:
         return None, {"file": "profiles/r03_traffic.json", "stale": True,
                       "note": "collected on another version of correlation_mfma.hip: not reported"}

@@ -24,7 +24,7 @@ B, C, H8, W8, D = 32, 256, 48, 160, 441
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_round.sh) on tools/corr_only.py, "
               "B=32 [32,256,48,160]; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); KB -> bytes x1024",
-    "kernel_source_sha16": hashlib.sha256(open(src, "rb").read()).hexdigest()[:16],
+    "kernel_source_sha16": hashlib.sha256(open(src, "rb").read() + open(os.path.join(os.path.dirname(src), "corr_bwd4_asm.inc"), "rb").read()).hexdigest()[:16],
     "per_launch_kb": mean,
     "corr_fwd": {"hbm_bytes": hbm("fwd"), "algorithmic_bytes": 4.0 * B * H8 * W8 * (2 * C + D)},
     "corr_bwd_both_launches": {"hbm_bytes": hbm("bwd_wrt0") + hbm("bwd_wrt1"), "algorithmic_bytes": 4.0 * B * H8 * W8 * (D + 4 * C),
