@@ -186,9 +186,11 @@ def test_seeded_extensions(seeded, dev):
     ((1, 256, 100, 36), dict()),
     ((2, 128, 30, 20), dict()),
     # more items than CUs with two- and three-row classes: a workgroup walks on to its next item
-    # while the DMA already runs two rows ahead (the row barrier sits inside the row)
+    # while the DMA already runs a row ahead (the row barrier sits inside the row)
     ((130, 128, 4, 8), dict()),
     ((66, 256, 5, 8), dict()),
+    # C % 128 == 0 but not a power of two: the tile stores divide by C instead of multiplying by 1/C
+    ((2, 384, 13, 20), dict()),
     ((2, 6, 10, 12), dict(kernel_size=3, max_displacement=4, pad=3, stride_1=2, stride_2=2)),
     ((1, 5, 9, 11), dict(kernel_size=1, max_displacement=5, pad=2, stride_1=1, stride_2=2)),
     ((1, 4, 12, 9), dict(kernel_size=5, max_displacement=3, pad=6, stride_1=3, stride_2=1)),
