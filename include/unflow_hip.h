@@ -199,6 +199,10 @@ int unflow_create_mask(float *mask, int B, int H, int W, int pad_top, int pad_bo
  * not NULL it is multiplied by (1 - occ) (losses.py:53-55). */
 int unflow_fb_occlusion(const float *flow, const float *flow_other_warped, float *flow_diff,
                         float *occ, float *mask_inout, int B, int H, int W, unflow_stream_t stream);
+/* The same with the mask product written somewhere else: mask_out = mask_in * (1 - occ) (both NULL or both given;
+ * they may be the same buffer).  Saves the caller the copy of a shared border mask per flow direction and level. */
+int unflow_fb_occlusion_masked(const float *flow, const float *flow_other_warped, float *flow_diff, float *occ,
+                               const float *mask_in, float *mask_out, int B, int H, int W, unflow_stream_t stream);
 /* The same with flow_other_warped = image_warp(flow_other, flow) (losses.py:38-39) computed on
  * the fly; flow_other_warped (optional output), occ and mask_out may be NULL.
  * mask_out = mask_in * (1 - occ) (losses.py:53-55); mask_in may be the same buffer.

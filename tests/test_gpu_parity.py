@@ -567,6 +567,17 @@ def test_charbonnier_and_masks_vs_oracle(oracle_mod, dev):
     wd, wo = oracle_mod.fb_occlusion(f, w)
     close(diff, wd, 0, 0)
     np.testing.assert_array_equal(N(occ), wo)
+    # the mask product of compute_losses (losses.py:53-55): in place, and with a separate input (unflow_fb_occlusion_masked)
+    m = rng.random((2, 9, 11, 1)).astype(np.float32)
+    m_inplace = T(m, dev)
+    losses.fb_occlusion(T(f, dev), T(w, dev), m_inplace)
+    np.testing.assert_array_equal(N(m_inplace), m * (1 - wo))
+    m_src, m_out = T(m, dev), torch.full((2, 9, 11, 1), float("nan"), device=dev)
+    losses.fb_occlusion(T(f, dev), T(w, dev), m_out, mask_in=m_src)
+    np.testing.assert_array_equal(N(m_out), m * (1 - wo))
+    np.testing.assert_array_equal(N(m_src), m)
+    with pytest.raises(ValueError):
+        losses.fb_occlusion(T(f, dev), T(w, dev), None, mask_in=m_src)
 
 
 @pytest.mark.parametrize("B,H,W", [(2, 40, 56), (1, 9, 33), (3, 8, 32), (1, 1, 1), (1, 2, 70), (2, 17, 3)])

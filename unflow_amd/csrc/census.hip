@@ -679,13 +679,13 @@ __device__ inline float fb_occluded(float2 f, float2 w, float2 m, float &du, flo
 __global__ __launch_bounds__(256) void fb_occlusion_kernel(const float2 *__restrict__ flow,
                                                            const float2 *__restrict__ other,
                                                            float2 *__restrict__ flow_diff, float *__restrict__ occ,
-                                                           float *__restrict__ mask_inout, long long n) {
+                                                           const float *mask_in, float *mask_out, long long n) {
   for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
     float du, dv;
     const float o = fb_occluded(flow[p], other[p], other[p], du, dv);
     if (flow_diff) flow_diff[p] = make_float2(du, dv);
     if (occ) occ[p] = o;
-    if (mask_inout) mask_inout[p] = mask_inout[p] * (1.f - o);
+    if (mask_out) mask_out[p] = mask_in[p] * (1.f - o);      // (mask_in may be mask_out: read, then written, by the same lane)
   }
 }
 
@@ -1052,7 +1052,19 @@ extern "C" int unflow_fb_occlusion(const float *flow, const float *flow_other_wa
   if (n <= 0) return n == 0 ? UNFLOW_OK : fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion: negative dimension");
   hipLaunchKernelGGL(fb_occlusion_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other_warped),
-                     reinterpret_cast<float2 *>(flow_diff), occ, mask_inout, n);
+                     reinterpret_cast<float2 *>(flow_diff), occ, mask_inout, mask_inout, n);
+  return launch_status("fb_occlusion");
+}
+
+extern "C" int unflow_fb_occlusion_masked(const float *flow, const float *flow_other_warped, float *flow_diff, float *occ,
+                                          const float *mask_in, float *mask_out, int B, int H, int W, unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (n <= 0) return n == 0 ? UNFLOW_OK : fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion: negative dimension");
+  if ((mask_in == nullptr) != (mask_out == nullptr))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion: mask_in and mask_out go together");
+  hipLaunchKernelGGL(fb_occlusion_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other_warped),
+                     reinterpret_cast<float2 *>(flow_diff), occ, mask_in, mask_out, n);
   return launch_status("fb_occlusion");
 }
 

@@ -149,10 +149,11 @@ def create_outgoing_mask(flow):
     return mask
 
 
-def fb_occlusion(flow, flow_other_warped, mask_inout=None):
+def fb_occlusion(flow, flow_other_warped, mask_inout=None, mask_in=None):
     """(flow_diff, occ) of losses.py:38-51; multiplies mask_inout by (1-occ) in place
-    when given (losses.py:53-55).  occ and the mask carry no gradient; flow_diff
-    is returned detached (use ``flow + flow_other_warped`` for a differentiable one)."""
+    when given (losses.py:53-55).  With ``mask_in`` the product ``mask_in * (1 - occ)`` is written
+    to ``mask_inout`` instead (no copy of a shared border mask).  occ and the mask carry no gradient;
+    flow_diff is returned detached (use ``flow + flow_other_warped`` for a differentiable one)."""
     flow = _dev(flow.detach(), "flow")
     other = _dev(flow_other_warped.detach(), "flow_other_warped")
     _check_flow(None, flow)
@@ -160,8 +161,14 @@ def fb_occlusion(flow, flow_other_warped, mask_inout=None):
     diff = torch.empty_like(flow)
     occ = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
     with torch.cuda.device(flow.device):
-        _lib.check(_lib.load().unflow_fb_occlusion(_ptr(flow), _ptr(other), _ptr(diff), _ptr(occ),
-                                                   _ptr(mask_inout), B, H, W, _stream()))
+        if mask_in is not None:
+            if mask_inout is None:
+                raise ValueError("fb_occlusion: mask_in needs mask_inout to write the product to")
+            _lib.check(_lib.load().unflow_fb_occlusion_masked(_ptr(flow), _ptr(other), _ptr(diff), _ptr(occ),
+                                                              _ptr(_dev(mask_in, "mask_in")), _ptr(mask_inout), B, H, W, _stream()))
+        else:
+            _lib.check(_lib.load().unflow_fb_occlusion(_ptr(flow), _ptr(other), _ptr(diff), _ptr(occ),
+                                                       _ptr(mask_inout), B, H, W, _stream()))
     return diff, occ
 
 
@@ -592,11 +599,10 @@ def compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occl
         disocc_fw = (dens_fw < DISOCC_THRESH).float()
         disocc_bw = (dens_bw < DISOCC_THRESH).float()
 
-    fused_fb = mask_occlusion == 'fb' and not (want('fb') or return_aux)
     if border_mask is None:
         mask_fw = create_outgoing_mask(flow_fw)
         mask_bw = create_outgoing_mask(flow_bw)
-    elif fused_fb:       # the occlusion kernel writes border_mask * (1 - occ) into fresh buffers: no copies
+    elif mask_occlusion == 'fb':       # the occlusion kernels write border_mask * (1 - occ) into fresh buffers: no copies
         mask_fw = torch.empty_like(border_mask)
         mask_bw = torch.empty_like(border_mask)
     else:
@@ -607,8 +613,9 @@ def compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occl
     if want('fb') or return_aux:
         flow_bw_warped = image_warp(bw[4], fw[3])
         flow_fw_warped = image_warp(fw[4], bw[3])
-        diff_fw, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if mask_occlusion == 'fb' else None)
-        diff_bw, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if mask_occlusion == 'fb' else None)
+        fb = mask_occlusion == 'fb'
+        diff_fw, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if fb else None, mask_in=border_mask if fb else None)
+        diff_bw, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if fb else None, mask_in=border_mask if fb else None)
     elif mask_occlusion == 'fb':
         src = border_mask if border_mask is not None else None
         _, fb_occ_fw = fb_occlusion_warp(flow_fw, flow_bw, mask_fw, mask_in=src)
