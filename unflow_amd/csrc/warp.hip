@@ -489,8 +489,11 @@ template <int C, bool CLAMP, class T = float>   // gradient with respect to the 
 __global__ __launch_bounds__(kBlock) void warp_bwd_flow_fast_kernel(const T *__restrict__ grad,
                                                                     const T *__restrict__ images,
                                                                     const typename FlowOf<T>::type *__restrict__ flows,
-                                                                    typename FlowOf<T>::type *__restrict__ d_flow, int H, int W, int ntx,
+                                                                    typename FlowOf<T>::type *__restrict__ d_flow,
+                                                                    float *__restrict__ zero_out, int H, int W, int ntx,
                                                                     int nty) {
+  // zero_out (optional, [B,H,W,C] floats): zeroed pixel by pixel on the way -- the image gradient of image_warp is a
+  // scatter-add into a zeroed buffer, and this kernel runs in front of it (one launch instead of a memset + this)
   const FastTile ft = fast_tile(H, W, ntx, nty);
   const T *base = images + ft.item_px * C;
   const T *gin = grad + ft.item_px * C;
@@ -586,6 +589,11 @@ __global__ __launch_bounds__(kBlock) void warp_bwd_flow_fast_kernel(const T *__r
       d = make_float2(du, dv);
     }
     if (ok[i]) nt_store2(d, dout + pix[i]);
+    if (zero_out && ok[i]) {
+      float *z = zero_out + (ft.item_px + pix[i]) * C;
+#pragma unroll
+      for (int c = 0; c < C; ++c) z[c] = 0.f;
+    }
   }
 }
 
@@ -1246,7 +1254,7 @@ extern "C" int unflow_backward_warp_bwd(const float *input_grad, const float *im
   hipStream_t s = as_stream(stream);
   if (fast_ok(B, H, W, C)) {
     FAST_LAUNCH(warp_bwd_flow_fast_kernel, false, input_grad, images, reinterpret_cast<const float2 *>(flows),
-                reinterpret_cast<float2 *>(output_grad));
+                reinterpret_cast<float2 *>(output_grad), (float *)nullptr);
     return launch_status("backward_warp_bwd");
   }
   const unsigned grid = grid_for(vtotal);
@@ -1278,7 +1286,12 @@ extern "C" int unflow_image_warp_bwd(const float *grad, const float *im, const f
   const long long vtotal = tiled_total(B, H, W);   // the kernels walk 64x4 pixel tiles
   if (total == 0 || (!d_im && !d_flow)) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
-  if (d_im && C > 0) {
+  // The image gradient is a scatter-add into a zeroed buffer.  When the flow gradient is wanted too and goes through
+  // the tiled kernel, that kernel runs FIRST and zeroes d_im on the way (it visits every pixel once): one launch
+  // less than a memset in front of the pair.
+  const bool tiled_im = d_im && C >= 1 && C <= 3 && B <= 65535;
+  const bool zero_in_flow_kernel = tiled_im && d_flow && fast_ok(B, H, W, C);
+  if (d_im && C > 0 && !zero_in_flow_kernel) {
     if (hipMemsetAsync(d_im, 0, sizeof(float) * (size_t)total * C, s) != hipSuccess)
       return launch_status("image_warp_bwd memset");
   }
@@ -1293,22 +1306,19 @@ extern "C" int unflow_image_warp_bwd(const float *grad, const float *im, const f
     case 3: IW_BWD(3, IM_, FL_); break;      \
     default: IW_BWD(0, IM_, FL_);            \
   }
-  if (d_im && C >= 1 && C <= 3 && B <= 65535) {
+  if (tiled_im) {
     // image gradient through the LDS-privatised scatter; the flow gradient (if wanted) separately
     const dim3 tg((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B), tg8((W + kSX - 1) / kSX, (H + 7) / 8, B);
     const float2 *fl = reinterpret_cast<const float2 *>(flow);
+    if (zero_in_flow_kernel) FAST_LAUNCH(warp_bwd_flow_fast_kernel, true, grad, im, fl, reinterpret_cast<float2 *>(d_flow), d_im);
     if (C == 1) hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<1, kSY>), tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
     else if (C == 2) hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<2, kSY>), tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
     else hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<3, 8>), tg8, dim3(kSX * 8), 0, s, grad, fl, d_im, H, W);
-    if (d_flow) {
-      if (fast_ok(B, H, W, C))
-        FAST_LAUNCH(warp_bwd_flow_fast_kernel, true, grad, im, fl, reinterpret_cast<float2 *>(d_flow));
-      else { IW_BWD_C(false, true) }
-    }
+    if (d_flow && !zero_in_flow_kernel) { IW_BWD_C(false, true) }
   } else if (d_im && d_flow) { IW_BWD_C(true, true) }
   else if (d_im) { IW_BWD_C(true, false) }
   else if (fast_ok(B, H, W, C)) {
-    FAST_LAUNCH(warp_bwd_flow_fast_kernel, true, grad, im, reinterpret_cast<const float2 *>(flow), reinterpret_cast<float2 *>(d_flow));
+    FAST_LAUNCH(warp_bwd_flow_fast_kernel, true, grad, im, reinterpret_cast<const float2 *>(flow), reinterpret_cast<float2 *>(d_flow), (float *)nullptr);
   } else { IW_BWD_C(false, true) }
 #undef IW_BWD_C
 #undef IW_BWD
@@ -1386,7 +1396,7 @@ extern "C" int unflow_backward_warp_bwd_f16(const void *input_grad, const void *
   hipStream_t s = as_stream(stream);
   FAST_LAUNCH_F16(warp_bwd_flow_fast_kernel, false, static_cast<const _Float16 *>(input_grad),
                   static_cast<const _Float16 *>(images), static_cast<const f16x2_t *>(flows),
-                  static_cast<f16x2_t *>(output_grad));
+                  static_cast<f16x2_t *>(output_grad), (float *)nullptr);
   return launch_status("backward_warp_bwd_f16");
 }
 
@@ -1408,7 +1418,7 @@ extern "C" int unflow_image_warp_bwd_flow_f16(const void *grad, const void *im, 
   UNFLOW_F16_ALIGNED("image_warp_grad", grad, im, flow, d_flow);
   hipStream_t s = as_stream(stream);
   FAST_LAUNCH_F16(warp_bwd_flow_fast_kernel, true, static_cast<const _Float16 *>(grad), static_cast<const _Float16 *>(im),
-                  static_cast<const f16x2_t *>(flow), static_cast<f16x2_t *>(d_flow));
+                  static_cast<const f16x2_t *>(flow), static_cast<f16x2_t *>(d_flow), (float *)nullptr);
   return launch_status("image_warp_bwd_flow_f16");
 }
 
