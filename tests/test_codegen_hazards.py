@@ -23,6 +23,26 @@ def test_scanner_flags_the_pattern_and_only_the_pattern():
     assert len(chk.scan(glob, "t")) == 1
 
 
+def test_scanner_counts_wait_states_and_follows_branches():
+    # s_nop 1 is two wait states: the write behind it is safe
+    nop1 = ["_ZN6kernelE:", "\tbuffer_store_dwordx4 v[4:7], v63, s[36:39], s0 offen", "\ts_nop 1", "\tv_mov_b32_e32 v4, 0"]
+    assert chk.scan(nop1, "t") == []
+    # a branch inside the window: the scan goes on at its target (objdump listings carry the addresses)
+    def listing(branch):
+        return ["0000000000001000 <_Zkern>:",
+                "\tbuffer_store_dwordx4 v[4:7], v1, s[0:3], s5 offen  // 000000001000: E07C1000 05000401",
+                "\t%s  // 000000001008: BF820002" % branch,
+                "\tv_mov_b32_e32 v9, 0   // 00000000100C: 7E120280",
+                "\tv_mov_b32_e32 v9, 0   // 000000001010: 7E120280",
+                "\tv_mov_b32_e32 v4, 0   // 000000001014: 7E080280"]
+    assert len(chk.scan(listing("s_branch 2"), "t")) == 1
+    assert len(chk.scan(listing("s_cbranch_scc1 2"), "t")) == 1
+    assert chk.scan(listing("s_nop 1"), "t") == []
+    # without addresses the successor is unknown: reported
+    unknown = ["_ZN6kernelE:", "\tbuffer_store_dwordx4 v[4:7], v63, s[36:39], s0 offen", "\ts_branch 12", "\tv_mov_b32_e32 v8, 0"]
+    assert len(chk.scan(unknown, "t")) == 1
+
+
 def test_the_shipped_library_has_no_store_data_hazard():
     so = os.path.join(ROOT, "unflow_amd", "libunflow_hip.so")
     assert os.path.exists(so), "build the library first (__graft_entry__.build())"

@@ -16,7 +16,7 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 STORE = re.compile(r"^\s*((?:buffer|global|flat|scratch)_store_(?:dwordx[34]|b96|b128))\s+(.*)$")
-WINDOW = 2       # instructions after the store that must not write its data registers
+WINDOW = 2       # wait states after the store in which its data registers must not be written (s_nop N = N + 1 states)
 
 
 def _regs(tok):
@@ -38,11 +38,14 @@ def _valu_dst(text):
 
 
 def scan(lines, name):
+    """Walks every path of up to WINDOW wait states behind a wide store: straight on, and through branches whose target
+    the listing gives (objdump prints the address of every instruction; a branch's operand is its 16-bit dword offset)."""
     found = []
     kern = "?"
-    code = []
+    code = []      # (kernel, text, address or None)
     for raw in lines:
-        t = raw.split("//")[0].rstrip()
+        parts = raw.split("//")
+        t = parts[0].rstrip()
         m = re.match(r"^(?:[0-9a-f]+ )?<?(_Z\w+)>?:", t.strip())     # kernel label (.s) or symbol line (objdump)
         if m:
             kern = m.group(1)
@@ -50,16 +53,43 @@ def scan(lines, name):
         s = t.strip()
         if not s or s.startswith((";", ".")) or s.endswith(":"):
             continue
-        code.append((kern, s))
-    for i, (kern, s) in enumerate(code):
+        am = re.match(r"\s*([0-9A-Fa-f]+):", parts[1]) if len(parts) > 1 else None
+        code.append((kern, s, int(am.group(1), 16) if am else None))
+    at = {a: i for i, (_, _, a) in enumerate(code) if a is not None}
+
+    def walk(store, data, i, states, seen):
+        while states < WINDOW and i < len(code):
+            nxt = code[i][1]
+            if _valu_dst(nxt) & data:
+                found.append("%s [%s]: %s   -> %s" % (name, code[store][0][:80], code[store][1], nxt))
+                return
+            if nxt.startswith("s_endpgm"):
+                return
+            bm = re.match(r"s_(c?branch\w*)\s+(\d+)", nxt)
+            if bm or re.match(r"s_(setpc|swappc)", nxt):
+                tgt = None
+                if bm and code[i][2] is not None:
+                    off = int(bm.group(2))
+                    tgt = at.get(code[i][2] + 4 + 4 * (off - 65536 if off >= 32768 else off))
+                if tgt is None:
+                    found.append("%s [%s]: %s   -> %s (branch inside the hazard window, target unknown)" % (name, code[store][0][:80], code[store][1], nxt))
+                    return
+                if (tgt, states) not in seen:
+                    seen.add((tgt, states))
+                    walk(store, data, tgt, states + 1, seen)
+                if nxt.startswith("s_branch"):
+                    return
+            m2 = re.match(r"s_nop\s+(\d+)", nxt)
+            states += int(m2.group(1)) + 1 if m2 else 1
+            i += 1
+
+    for i, (kern, s, _) in enumerate(code):
         m = STORE.match(s)
         if not m:
             continue
         ops = [x.strip() for x in m.group(2).split(",")]
         data = _regs(ops[0]) if m.group(1).startswith("buffer") else (_regs(ops[1]) if len(ops) > 1 else set())
-        for n in range(1, WINDOW + 1):
-            if i + n < len(code) and _valu_dst(code[i + n][1]) & data:
-                found.append("%s [%s]: %s   -> +%d: %s" % (name, kern[:80], s, n, code[i + n][1]))
+        walk(i, data, i + 1, 0, set())
     return found
 
 

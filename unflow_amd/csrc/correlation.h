@@ -20,6 +20,10 @@ bool corr_mfma_supported(const CorrGeometry &g, int C);
 bool corr_mfma_bwd_supported(const CorrGeometry &g, int C);
 int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, const CorrGeometry &g,
                   hipStream_t s);
+// second-generation forward (correlation_fwd2.hip): the channel sweep as one hand-written instruction stream.  Needs
+// C % 16 == 0, W % 4 == 0 and 16-byte aligned tensors; everything else takes corr_mfma_fwd's kernels.
+bool corr_fwd2_supported(const CorrGeometry &g, int C, const void *in0, const void *in1, const void *out);
+int corr_fwd2(const float *in0, const float *in1, float *out, int B, int C, const CorrGeometry &g, hipStream_t s);
 // fp16 storage, f32 MFMA (extension): half in, half out, every product and the k-ordered f32 sum exact
 int corr_mfma_fwd_f16(const void *in0, const void *in1, void *out, int B, int C, const CorrGeometry &g,
                       hipStream_t s);

@@ -1,0 +1,216 @@
+// FlowNetC correlation forward (kernel_size 1, stride_1 1, stride_2 2, pad == max_displacement == 20) on the f32
+// matrix cores of gfx950 -- second generation: the channel sweep is ONE hand-written instruction stream.
+//
+// Reference semantics: ops/correlation_op.cu.cc:51-117 (CorrelateData) + :30-49 (blob_rearrange_kernel2) of the
+// reference checkout.  Formulation, exactness and staging are those of correlation_mfma.hip (header there): four
+// parity classes, per class a dense GEMM G[4x4 positions x 24x24 window] = f0s . f1s on v_mfma_f32_16x16x4_f32,
+// operands staged by LDS-DMA in NCHW row order, half-window workgroups so that two share a CU.
+//
+// What is different from corr_mfma_fwd_half_kernel:
+//  * a wave owns BOTH column classes of its 4x4 tile of class positions and three of the six N-tile columns (waves =
+//    tile column tx x tile row ty x column half nh).  The LDS images keep the full-resolution row order, so the two
+//    floats of one ds_read_b64 are the same class column in class 0 and class 1: one fragment read feeds two MFMAs
+//    (10 LDS reads per 18 MFMAs instead of 19).  Plane stride 928 floats = 32 mod 64: the two channels a half-wave
+//    reads take disjoint halves of the 64 banks, the reads are conflict free without the odd-plane shift (which would
+//    break the 8-byte alignment).
+//  * the sweep over the channels -- zeroing, prologue DMA, per chunk of 8 channels 36 MFMAs + 20 fragment reads (one
+//    K-step ahead, double-buffered registers) + 5 LDS-DMA pieces (two chunks ahead) + one barrier -- is one asm
+//    statement on fixed registers (tools/gen_corr_fwd_asm.py -> corr_fwd2_asm.inc): ~0.9 scalar and no vector ALU
+//    instruction per MFMA where the compiled loop had 2.1 + 1.2.  The accumulators are the statement's outputs, bound
+//    to their registers, and the epilogue is C++ again.
+//  * epilogue: per N-tile row the results go to an LDS slab [position row 8][window row 4][dx' + 3: 28][x 16 + 2] with
+//    one unmasked ds_write_b64 per (tile, position column) -- out-of-range dx' land in pad cells that are never read,
+//    the pitches (18, 28 * 18) make the 16 lanes of a write group hit 16 different bank pairs -- and leave as 64-byte
+//    row segments (buffer stores; the range check drops the invalid ones).
+// Same sums in the same order as corr_mfma_fwd_half_kernel (k-ordered f32 chain over the channels, one scaling): the
+// results are bit-identical.
+#include "common.h"
+#include "correlation.h"
+#include "corr_fwd2_asm.inc"
+
+#include <atomic>
+#include <cstdint>
+#include <type_traits>
+
+namespace unflow {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const float lds_cf;
+
+constexpr int S = 2, R = 10, GW = 2 * R + 1, TP = 4;
+constexpr int RY = 8, RX = 8;                 // region of one row class in a workgroup: 2 x 2 tiles, both column classes
+constexpr int RW = S * RX;                    // 16 full-resolution columns
+constexpr int NTHREADS = 512;
+constexpr unsigned OOB = 0x80000000u;         // beyond any num_records (< 2 GiB): loads return 0, stores are dropped
+constexpr int ROWF = UNFLOW_FWD2_ROWF, ROWS = UNFLOW_FWD2_ROWS, PL = UNFLOW_FWD2_PL, F0S = UNFLOW_FWD2_F0S;
+constexpr int F0OFF = UNFLOW_FWD2_F0OFF, STAGE = UNFLOW_FWD2_STAGE, NT = UNFLOW_FWD2_NT;
+constexpr int KC = 8;
+static_assert(ROWF == S * (RX + 2 * R) && ROWS == RY + 8 && PL % 64 == 32 && F0S % 16 == 8, "LDS images");
+// epilogue slab of one N-tile row
+constexpr int XP = RW + 2;                    // 18: x pitch
+constexpr int DXP = 28;                       // dx' + 3 in 0..26
+constexpr int QS = DXP * XP;                  // 504: window-row pitch
+constexpr int RS = 4 * QS;                    // 2016: position-row pitch
+constexpr int SLAB = RY * RS;                 // 16128 floats
+static_assert(SLAB <= 2 * STAGE, "the slab reuses the staging buffers");
+constexpr size_t LDS_BYTES = sizeof(float) * 2 * STAGE;
+
+// A 16-byte store and the two wait states gfx950 needs before a VALU instruction may overwrite its data registers
+// (tools/check_store_hazard.py; the compiler pads nothing when the scalar offset is a register), as one statement so
+// that nothing can be scheduled in between.
+__device__ inline void store_b128(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+__device__ inline int xcd_remap(int b, int nblk) { return (nblk & 7) == 0 ? (b & 7) * (nblk >> 3) + (b >> 3) : b; }
+
+__global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__restrict__ in0, const float *__restrict__ in1,
+                                                                float *__restrict__ out, int C, int H, int W, int nbx,
+                                                                int nby) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nh = wave & 1, tx = (wave >> 1) & 1, ty = wave >> 2;
+  int vb = xcd_remap(blockIdx.x, gridDim.x);
+  const int half = vb & 1;                     // which three N-tile rows of the region's window
+  vb >>= 1;
+  const int bx = vb % nbx, by = (vb / nbx) % nby, bz = vb / (nbx * nby);
+  const int cy = bz & 1;
+  const long long item = bz >> 1;
+  const int ys0 = by * RY, xs0 = bx * RX;
+  const int hs = (H - cy + S - 1) / S;
+  if (ys0 >= hs) return;
+  const long long plane = (long long)H * W;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_cf *)lds;
+
+  // N-tile rows of this wave that meet the image (the others multiply zero padding: skipped)
+  unsigned rowmask = 0;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int r0 = ys0 + ty * TP - R + 4 * (3 * half + q);
+    if (r0 + 3 >= 0 && r0 < hs) rowmask |= 1u << q;
+  }
+  rowmask = (unsigned)__builtin_amdgcn_readfirstlane((int)rowmask);
+
+  f32x4 acc[NT];
+  {
+    const int k = lane >> 4, n = lane & 15;
+    const unsigned aaddr = lds0 + 4u * (unsigned)(F0OFF + k * F0S + (ty * TP + (n >> 2)) * RW + S * (tx * TP + (n & 3)));
+    const unsigned baddr = lds0 + 4u * (unsigned)(k * PL + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + 24 * nh);
+    // LDS-DMA: wave w stages channel w of the chunk -- 16 window rows of f1 (3 1/2 pieces of 1 KiB) and the 8 x 16
+    // positions of f0 (half a piece).  X and W are multiples of 4: a 16-byte segment is inside or outside as a whole;
+    // outside (zero padding) it reads beyond num_records and returns 0.
+    unsigned voff[5];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int f = (j * 64 + lane) * 4;
+      const int row = f / ROWF, x = f - row * ROWF;
+      const int Y = S * (ys0 - R + 12 * half + row) + cy, X = S * (xs0 - R) + x;
+      const bool in = f < ROWS * ROWF && Y >= 0 && Y < H && X >= 0 && X < W;
+      voff[j] = in ? (unsigned)((wave * plane + (long long)Y * W + X) * 4) : OOB;
+    }
+    {
+      const int f = (lane & 31) * 4;
+      const int row = f / RW, x = f - row * RW;
+      const int Y = S * (ys0 + row) + cy, X = S * xs0 + x;
+      voff[4] = Y < H && X < W ? (unsigned)((wave * plane + (long long)Y * W + X) * 4) : OOB;
+    }
+    const unsigned bytes = (unsigned)((long long)C * plane * 4);
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + item * C * plane), (short)0, (int)bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in1 + item * C * plane), (short)0, (int)bytes, 0x00020000);
+    const unsigned m1 = lds0 + 4u * (unsigned)(wave * PL), m0f = lds0 + 4u * (unsigned)(F0OFF + wave * F0S);
+    const unsigned cstep = (unsigned)(KC * plane * 4), npairs = (unsigned)(C / (2 * KC));
+    unsigned soff, cnt;
+    asm volatile(UNFLOW_FWD2_MAIN
+                 : UNFLOW_FWD2_ACC_OUTPUTS(acc), [soff] "=&s"(soff), [cnt] "=&s"(cnt)
+                 : [aaddr] "v"(aaddr), [baddr] "v"(baddr), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]),
+                   [v3] "v"(voff[3]), [v4] "v"(voff[4]), [r0] "s"(r0), [r1] "s"(r1), [mask] "s"(rowmask), [m1] "s"(m1),
+                   [m0f] "s"(m0f), [cstep] "s"(cstep), [npairs] "s"(npairs)
+                 : UNFLOW_FWD2_FRAG_CLOBBERS, "scc", "memory");
+  }
+
+  // ---- epilogue.  D layout of the MFMA: lane (py = lane >> 4, n = lane & 15), register j = position column;
+  // acc[(r * 3 + col) * 2 + c][j] = G[position (py, j) of class c][window (4 (3 half + r) + n / 4, 4 (3 nh + col) + n % 4)].
+  // (the thread id is made opaque here so that nothing of the epilogue's index arithmetic is computed in front of the
+  // main loop and carried across it: the loop leaves the compiler 16 registers)
+  unsigned tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const bool pow2 = (C & (C - 1)) == 0;
+  const float scale = 1.f / (float)C, fc = (float)C;
+  const int py = (tid & 63) >> 4, n = tid & 15;
+  // slab cell of (col 0, j 0): [row][n / 4][4 (3 nh) + n % 4 + 3][2 (4 tx)]; + col * 4 * XP, + j * (2 - XP)
+  float *const wr = lds + (ty * TP + py) * RS + (n >> 2) * QS + (12 * nh + (n & 3) + 3) * XP + S * TP * tx;
+  // readback: thread -> (c4: 4 columns, row, window row of the tile, dx' mod 4); dx' = dxg + 4 i
+  const int c4 = tid & 3, row = (tid >> 2) & 7, g = tid >> 5;
+  const int qr = g >> 2, dxg = g & 3;
+  const float *const rd = lds + row * RS + qr * QS + (dxg + 3) * XP + 4 * c4;
+  const int Y = S * (ys0 + row) + cy, X = S * xs0 + 4 * c4;
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + item * (GW * GW) * plane, (short)0,
+                                                                       (int)((long long)GW * GW * plane * 4), 0x00020000);
+  const int step4 = (int)(4 * plane * 4);      // four displacement planes on
+  __syncthreads();                              // every wave has read its last fragments
+  auto epilogue = [&](auto POW2) {
+    constexpr bool p2 = decltype(POW2)::value;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int col = 0; col < 3; ++col) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v0 = acc[(r * 3 + col) * 2 + 0][j], v1 = acc[(r * 3 + col) * 2 + 1][j];
+          const f32x2 v = p2 ? f32x2{v0 * scale, v1 * scale} : f32x2{v0 / fc, v1 / fc};
+          *reinterpret_cast<f32x2 *>(wr + col * 4 * XP + j * (2 - XP)) = v;
+        }
+      }
+      __syncthreads();
+      const int dy = 12 * half + 4 * r + qr - (row & 3);   // displacement row of (position row, window row)
+      const bool ok = dy >= 0 && dy <= 2 * R && Y < H && X < W;
+      const unsigned vo = ok ? (unsigned)((((long long)dy * GW + dxg) * plane + (long long)Y * W + X) * 4) : OOB;
+      const unsigned vo5 = dxg == 0 ? vo : OOB;    // i = 5: dx' = 20 + dxg
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const f32x2 lo = *reinterpret_cast<const f32x2 *>(rd + i * 4 * XP), hi = *reinterpret_cast<const f32x2 *>(rd + i * 4 * XP + 2);
+        const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
+        store_b128(v, ro, i == 5 ? vo5 : vo, (unsigned)(i * step4));
+      }
+      if (r < 2) __syncthreads();
+    }
+  };
+  if (pow2) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
+}
+
+constexpr int kMaxDevices = 64;
+
+}  // namespace
+
+bool corr_fwd2_supported(const CorrGeometry &g, int C, const void *in0, const void *in1, const void *out) {
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  // whole chunk pairs (the channel tail would need the buffer range check, which the scalar chunk offset bypasses),
+  // 16-byte row segments, one pair's tensors inside a 2 GiB buffer descriptor
+  return corr_mfma_supported(g, C) && C % (2 * KC) == 0 && g.W % 4 == 0 && al16(in0) && al16(in1) && al16(out) &&
+         (long long)GW * GW * g.H * g.W * 4 < (1LL << 31);
+}
+
+int corr_fwd2(const float *in0, const float *in1, float *out, int B, int C, const CorrGeometry &g, hipStream_t s) {
+  const int H = g.H, W = g.W;
+  const int hs = (H + S - 1) / S, ws = (W + S - 1) / S;
+  const int nbx = (ws + RX - 1) / RX, nby = (hs + RY - 1) / RY;
+  static std::atomic<bool> granted[kMaxDevices];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return launch_status("correlation_fwd (mfma, instruction blocks)");
+  const bool tracked = dev >= 0 && dev < kMaxDevices;
+  if (!(tracked && granted[dev].load(std::memory_order_acquire))) {
+    const hipError_t st = hipFuncSetAttribute(reinterpret_cast<const void *>(corr_fwd2_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
+    if (st != hipSuccess)
+      return fail(UNFLOW_ERR_LAUNCH, "correlation_fwd: cannot reserve %zu B of LDS (%s)", LDS_BYTES, hipGetErrorString(st));
+    if (tracked) granted[dev].store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL(corr_fwd2_kernel, dim3(nbx * nby * B * S * 2), dim3(NTHREADS), LDS_BYTES, s, in0, in1, out, C, H, W, nbx, nby);
+  return launch_status("correlation_fwd (mfma, instruction blocks)");
+}
+
+}  // namespace unflow

@@ -1675,6 +1675,9 @@ bool corr_mfma_bwd_supported(const CorrGeometry &g, int C) {
 
 int corr_mfma_fwd(const float *in0, const float *in1, float *out, int B, int C, const CorrGeometry &g,
                   hipStream_t s) {
+#ifndef UNFLOW_TUNE_OLD_FWD
+  if (corr_fwd2_supported(g, C, in0, in1, out)) return corr_fwd2(in0, in1, out, B, C, g, s);
+#endif
   const int H = g.H, W = g.W;
   const int hs = (H + S - 1) / S, ws = (W + S - 1) / S;
   const int nbx = (ws + RX - 1) / RX, nby = (hs + RY - 1) / RY;
@@ -1797,6 +1800,9 @@ const char *tune_flags_correlation_mfma() {
 #endif
 #ifdef UNFLOW_TUNE_OLD_BWD
          " UNFLOW_TUNE_OLD_BWD"
+#endif
+#ifdef UNFLOW_TUNE_OLD_FWD
+         " UNFLOW_TUNE_OLD_FWD"
 #endif
       ;
 }
