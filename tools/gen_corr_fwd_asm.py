@@ -17,6 +17,11 @@ Register map (128 registers, two workgroups per CU):
   v[FB(p) + 2 + 2 * (r * 3 + col) + c]  B fragments
 Run after changing anything here:  python tools/gen_corr_fwd_asm.py"""
 import os
+import sys
+
+# Diagnostic / schedule knobs (environment; tools/fwd2_variants.sh builds such variants into unflow_amd/variants/ and the
+# kernel reports them through unflow_build_flags()).  The shipped include is generated with none set.
+KNOBS = {k: os.environ.get("FWD2_" + k, "") for k in ("NODMA", "NOREADS", "NOBARRIER", "NOSKIP", "DMAFIRST", "PRIO", "STAMPS", "OUT")}
 
 # ---- LDS layout of a stage (floats), shared with correlation_fwd2.hip through the generated constants
 ROWF = 56                 # one staged window row at full resolution (both column classes)
@@ -51,11 +56,15 @@ def lit(lines):
     return " \\\n".join('  "%s\\n\\t"' % l for l in lines)
 
 
-def read_a(p, stage, kk):
+def read_a(p, stage, kk, first=False):
+    if KNOBS["NOREADS"] and not first:
+        return "s_nop 0"
     return "ds_read_b64 v[%d:%d], %%[aaddr] offset:%d" % (fb(p), fb(p) + 1, stage * SB + kk * 4 * F0S * 4)
 
 
-def read_b(p, stage, kk, r, col):
+def read_b(p, stage, kk, r, col, first=False):
+    if KNOBS["NOREADS"] and not first:
+        return "s_nop 0"
     reg = fb(p) + 2 + 2 * (r * NCOL + col)
     off = stage * SB + kk * 4 * PL * 4 + r * 4 * ROWF * 4 + col * 8 * 4
     assert off < 65536
@@ -70,7 +79,7 @@ def mfma(p, r, col, c):
 def group(p, r, nxt, label):
     """The 6 MFMAs of N-tile row r on fragment buffer p, with the reads of the same row for the NEXT K-step
     (nxt = (stage, kk), into buffer 1 - p) behind the first three; skipped as a whole when the row lies in the padding."""
-    L = ["s_bitcmp0_b32 %%[mask], %d" % r, "s_cbranch_scc1 %df" % label]
+    L = [] if KNOBS["NOSKIP"] else ["s_bitcmp0_b32 %%[mask], %d" % r, "s_cbranch_scc1 %df" % label]
     k = 0
     for col in range(NCOL):
         for c in range(2):
@@ -83,11 +92,15 @@ def group(p, r, nxt, label):
 
 
 def dma_f1(j, stage):
+    if KNOBS["NODMA"] == "1" or (KNOBS["NODMA"] == "half" and j in (1, 3)):
+        return []
     return ["s_add_u32 m0, %%[m1], %d" % (stage * SB + j * 1024), "s_nop 0",
             "buffer_load_dwordx4 %%[v%d], %%[r1], %%[soff] offen lds" % j]
 
 
 def dma_f0(stage):
+    if KNOBS["NODMA"] == "1":
+        return []
     return ["s_add_u32 m0, %%[m0f], %d" % (stage * SB), "s_nop 0",
             "buffer_load_dwordx4 %[v4], %[r0], %[soff] offen lds"]
 
@@ -105,13 +118,24 @@ def chunk(s, base):
     L = ["s_waitcnt lgkmcnt(0)", read_a(1, s, 1)]
     for r in range(NROW):
         L += group(0, r, (s, 1), base + r)
-    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier", read_a(0, 1 - s, 0),
+    if KNOBS["STAMPS"]:     # cycles a wave spends waiting for its DMA / at the barrier (s[90:94] are named as clobbers)
+        L += ["s_memtime s[90:91]", "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_memtime s[92:93]", "s_waitcnt lgkmcnt(0)",
+              "s_sub_u32 s94, s92, s90", "s_add_u32 %[accv], %[accv], s94", "s_barrier", "s_memtime s[90:91]", "s_waitcnt lgkmcnt(0)",
+              "s_sub_u32 s94, s90, s92", "s_add_u32 %[accb], %[accb], s94"]
+    else:
+        L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"] + ([] if KNOBS["NOBARRIER"] else ["s_barrier"])
+    L += [read_a(0, 1 - s, 0),
           "s_cmp_lg_u32 %[cnt], 1", "s_cbranch_scc0 %df" % (base + 9)]
     # with DMA (a chunk after next exists)
-    L += group(1, 0, (1 - s, 0), base + 3) + dma_f1(0, s) + dma_f1(1, s)
-    L += group(1, 1, (1 - s, 0), base + 4) + dma_f1(2, s)
-    L += group(1, 2, (1 - s, 0), base + 5) + ["s_mov_b32 exec_hi, 0"] + dma_f1(3, s) + dma_f0(s) + ["s_mov_b32 exec_hi, -1",
-                                                                                                       "s_add_u32 %[soff], %[soff], %[cstep]"]
+    if KNOBS["DMAFIRST"]:
+        L += dma_all(s) + ["s_add_u32 %[soff], %[soff], %[cstep]"]
+        for r in range(NROW):
+            L += group(1, r, (1 - s, 0), base + 3 + r)
+    else:
+        L += group(1, 0, (1 - s, 0), base + 3) + dma_f1(0, s) + dma_f1(1, s)
+        L += group(1, 1, (1 - s, 0), base + 4) + dma_f1(2, s)
+        L += group(1, 2, (1 - s, 0), base + 5) + ["s_mov_b32 exec_hi, 0"] + dma_f1(3, s) + dma_f0(s) + ["s_mov_b32 exec_hi, -1",
+                                                                                                           "s_add_u32 %[soff], %[soff], %[cstep]"]
     L += ["s_branch %df" % (base + 10), "%d:" % (base + 9)]
     # without (the last two chunks)
     for r in range(NROW):
@@ -124,7 +148,7 @@ def main_loop():
     L = ["v_mov_b32 v%d, 0" % r for r in range(ACC0, LAST + 1)]
     L += ["s_mov_b32 %[soff], 0"] + dma_all(0) + ["s_add_u32 %[soff], %[soff], %[cstep]"] + dma_all(1)
     L += ["s_add_u32 %[soff], %[soff], %[cstep]", "s_mov_b32 %[cnt], %[npairs]", "s_waitcnt vmcnt(5)", "s_barrier"]
-    L += [read_a(0, 0, 0)] + [read_b(0, 0, 0, r, col) for r in range(NROW) for col in range(NCOL)]
+    L += [read_a(0, 0, 0, True)] + [read_b(0, 0, 0, r, col, True) for r in range(NROW) for col in range(NCOL)]
     L += ["90:"] + chunk(0, 20) + chunk(1, 40)
     L += ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 90b"]
     # MFMA results -> any other reader: 11 wait states for an 8-pass MFMA; the compiler knows nothing of what is in flight
@@ -142,7 +166,16 @@ out.append("// the accumulators leave the statement as its outputs, bound to the
 out.append("#define UNFLOW_FWD2_ACC_OUTPUTS(A) " + ", ".join('"=&{v[%d:%d]}"(A[%d])' % (ACC0 + 4 * t, ACC0 + 4 * t + 3, t) for t in range(NT)))
 out.append("// operands: [aaddr] [baddr] [v0..v4] v; [r0] [r1] s (128 bit); [mask] [m1] [m0f] [cstep] [npairs] s; [soff] [cnt] =&s;")
 out.append("// clobbers the fragment registers, m0, scc, memory; EXEC is all ones on entry and exit")
+if KNOBS["STAMPS"]:
+    out.append('#define UNFLOW_FWD2_STAMP_OPERANDS , [accv] "+s"(accv), [accb] "+s"(accb)')
+    out.append('#define UNFLOW_FWD2_STAMP_CLOBBERS , "s90", "s91", "s92", "s93", "s94"')
+else:
+    out.append("#define UNFLOW_FWD2_STAMP_OPERANDS")
+    out.append("#define UNFLOW_FWD2_STAMP_CLOBBERS")
 out.append("#define UNFLOW_FWD2_MAIN \\\n%s" % lit(main_loop()))
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unflow_amd", "csrc", "corr_fwd2_asm.inc")
+path = KNOBS["OUT"] or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unflow_amd", "csrc", "corr_fwd2_asm.inc")
+flags = " ".join("FWD2_%s=%s" % (k, v) for k, v in sorted(KNOBS.items()) if v and k != "OUT")
+if flags:
+    out.insert(1, '#define UNFLOW_FWD2_GENERATOR_KNOBS "%s"' % flags)
 open(path, "w").write("\n".join(out) + "\n")
 print("wrote", path)

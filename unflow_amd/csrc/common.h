@@ -18,6 +18,7 @@ int fail(int code, const char *fmt, ...);
 // The UNFLOW_TUNE_* diagnostic knobs a translation unit was compiled with ("" for a production build); api.hip
 // joins them behind unflow_build_flags() so that a diagnostic build cannot pass for the real library.
 const char *tune_flags_correlation_mfma();
+const char *tune_flags_correlation_fwd2();
 const char *tune_flags_warp();
 
 // hipGetLastError() after a launch; never synchronises.

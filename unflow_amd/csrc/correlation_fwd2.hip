@@ -26,7 +26,11 @@
 // results are bit-identical.
 #include "common.h"
 #include "correlation.h"
+#ifdef UNFLOW_FWD2_INC          // a diagnostic variant of the instruction stream (tools/fwd2_variants.sh)
+#include UNFLOW_FWD2_INC
+#else
 #include "corr_fwd2_asm.inc"
+#endif
 
 #include <atomic>
 #include <cstdint>
@@ -64,6 +68,14 @@ __device__ inline void store_b128(f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned vo
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 
+#ifdef UNFLOW_TUNE_FWD2_STAMPS
+// Diagnostic build only (tools/fwd2_variants.sh, tools/stamps_fwd2.py): per wave of every 61st workgroup the shader
+// clock at the start / end of the channel sweep / end of the epilogue, the cycles spent waiting for its LDS-DMA and at
+// the chunk barriers, and the 100 MHz real-time counter around the kernel (the clock the chip held).
+constexpr int STAMP_SLOTS = 64, STAMP_WORDS = 8;
+__device__ unsigned long long g_fwd2_stamps[STAMP_SLOTS * 8 * STAMP_WORDS];
+#endif
+
 __device__ inline int xcd_remap(int b, int nblk) { return (nblk & 7) == 0 ? (b & 7) * (nblk >> 3) + (b >> 3) : b; }
 
 __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__restrict__ in0, const float *__restrict__ in1,
@@ -94,10 +106,19 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
   }
   rowmask = (unsigned)__builtin_amdgcn_readfirstlane((int)rowmask);
 
+#ifdef UNFLOW_TUNE_FWD2_STAMPS
+  unsigned long long st_t0 = 0, st_t1 = 0, st_r0 = 0;
+  unsigned st_v = 0, st_b = 0;
+#endif
   f32x4 acc[NT];
   {
     const int k = lane >> 4, n = lane & 15;
+#ifdef UNFLOW_FWD2_DIRECT_STORES
+    // M index of the MFMA = 4 * px + py: the D rows 4 * (lane >> 4) + j put the position COLUMN on the lanes
+    const unsigned aaddr = lds0 + 4u * (unsigned)(F0OFF + k * F0S + (ty * TP + (n & 3)) * RW + S * (tx * TP + (n >> 2)));
+#else
     const unsigned aaddr = lds0 + 4u * (unsigned)(F0OFF + k * F0S + (ty * TP + (n >> 2)) * RW + S * (tx * TP + (n & 3)));
+#endif
     const unsigned baddr = lds0 + 4u * (unsigned)(k * PL + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + 24 * nh);
     // LDS-DMA: wave w stages channel w of the chunk -- 16 window rows of f1 (3 1/2 pieces of 1 KiB) and the 8 x 16
     // positions of f0 (half a piece).  X and W are multiples of 4: a 16-byte segment is inside or outside as a whole;
@@ -117,18 +138,32 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
       const int Y = S * (ys0 + row) + cy, X = S * xs0 + x;
       voff[4] = Y < H && X < W ? (unsigned)((wave * plane + (long long)Y * W + X) * 4) : OOB;
     }
+#ifdef UNFLOW_TUNE_FWD2_OOBDMA       // timing only: every DMA lane out of range (zeros, nothing fetched)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) voff[j] = C > 0 ? OOB : voff[j];
+#endif
     const unsigned bytes = (unsigned)((long long)C * plane * 4);
     const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + item * C * plane), (short)0, (int)bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in1 + item * C * plane), (short)0, (int)bytes, 0x00020000);
     const unsigned m1 = lds0 + 4u * (unsigned)(wave * PL), m0f = lds0 + 4u * (unsigned)(F0OFF + wave * F0S);
     const unsigned cstep = (unsigned)(KC * plane * 4), npairs = (unsigned)(C / (2 * KC));
     unsigned soff, cnt;
+#ifdef UNFLOW_TUNE_FWD2_STAMPS
+    unsigned accv = 0, accb = 0;
+    st_t0 = __builtin_amdgcn_s_memtime();
+    st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     asm volatile(UNFLOW_FWD2_MAIN
-                 : UNFLOW_FWD2_ACC_OUTPUTS(acc), [soff] "=&s"(soff), [cnt] "=&s"(cnt)
+                 : UNFLOW_FWD2_ACC_OUTPUTS(acc), [soff] "=&s"(soff), [cnt] "=&s"(cnt) UNFLOW_FWD2_STAMP_OPERANDS
                  : [aaddr] "v"(aaddr), [baddr] "v"(baddr), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]),
                    [v3] "v"(voff[3]), [v4] "v"(voff[4]), [r0] "s"(r0), [r1] "s"(r1), [mask] "s"(rowmask), [m1] "s"(m1),
                    [m0f] "s"(m0f), [cstep] "s"(cstep), [npairs] "s"(npairs)
-                 : UNFLOW_FWD2_FRAG_CLOBBERS, "scc", "memory");
+                 : UNFLOW_FWD2_FRAG_CLOBBERS, "scc", "memory" UNFLOW_FWD2_STAMP_CLOBBERS);
+#ifdef UNFLOW_TUNE_FWD2_STAMPS
+    st_t1 = __builtin_amdgcn_s_memtime();
+    st_v = accv;
+    st_b = accb;
+#endif
   }
 
   // ---- epilogue.  D layout of the MFMA: lane (py = lane >> 4, n = lane & 15), register j = position column;
@@ -139,6 +174,44 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
   asm volatile("" : "+v"(tid));
   const bool pow2 = (C & (C - 1)) == 0;
   const float scale = 1.f / (float)C, fc = (float)C;
+#ifdef UNFLOW_FWD2_DIRECT_STORES
+  // Results leave straight from the accumulators: lane = (px = lane >> 4, window (qyl, qxl) = lane & 15), register j =
+  // position row; the two column classes of a position are adjacent floats of the output row -> one 8-byte store per
+  // (tile, j), four lanes (px) make 32 contiguous bytes.  Offsets below zero or beyond the 441 planes (dy' outside
+  // 0..20) fall to the buffer range check; dx' outside 0..20 and columns beyond W are sent there explicitly.
+  {
+    const int px = (tid & 63) >> 4, nn = tid & 15, qyl = nn >> 2, qxl = nn & 3;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + item * (GW * GW) * plane, (short)0,
+                                                                         (int)((long long)GW * GW * plane * 4), 0x00020000);
+    const int X = S * (xs0 + tx * TP + px);
+    const long long lane_off = (((long long)(12 * half + qyl) * GW + (12 * nh + qxl - px)) * plane + (long long)(S * (ys0 + ty * TP) + cy) * W + X) * 4;
+    int base[3];
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+      const int dx = 12 * nh + 4 * col + qxl - px;
+      base[col] = dx >= 0 && dx <= 2 * R && X < W ? (int)(lane_off + (long long)col * 16 * plane) : (int)0x40000000;
+    }
+    auto direct = [&](auto POW2) {
+      constexpr bool p2 = decltype(POW2)::value;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (S * (ys0 + ty * TP + j) + cy >= H) continue;        // (wave-uniform)
+          const int sc = (int)((((long long)(4 * r - j) * GW) * plane + (long long)S * j * W) * 4);
+#pragma unroll
+          for (int col = 0; col < 3; ++col) {
+            const float v0 = acc[(r * 3 + col) * 2 + 0][j], v1 = acc[(r * 3 + col) * 2 + 1][j];
+            const f32x2 v = p2 ? f32x2{v0 * scale, v1 * scale} : f32x2{v0 / fc, v1 / fc};
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), ro, base[col] + sc, 0, 0);
+          }
+        }
+      }
+    };
+    if (pow2) direct(std::true_type{});
+    else direct(std::false_type{});
+  }
+#else
   const int py = (tid & 63) >> 4, n = tid & 15;
   // slab cell of (col 0, j 0): [row][n / 4][4 (3 nh) + n % 4 + 3][2 (4 tx)]; + col * 4 * XP, + j * (2 - XP)
   float *const wr = lds + (ty * TP + py) * RS + (n >> 2) * QS + (12 * nh + (n & 3) + 3) * XP + S * TP * tx;
@@ -167,7 +240,11 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
       __syncthreads();
       const int dy = 12 * half + 4 * r + qr - (row & 3);   // displacement row of (position row, window row)
       const bool ok = dy >= 0 && dy <= 2 * R && Y < H && X < W;
+#ifdef UNFLOW_TUNE_FWD2_NOSTORE
+      const unsigned vo = ok && C < 0 ? (unsigned)((((long long)dy * GW + dxg) * plane + (long long)Y * W + X) * 4) : OOB;
+#else
       const unsigned vo = ok ? (unsigned)((((long long)dy * GW + dxg) * plane + (long long)Y * W + X) * 4) : OOB;
+#endif
       const unsigned vo5 = dxg == 0 ? vo : OOB;    // i = 5: dx' = 20 + dxg
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
@@ -178,8 +255,27 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
       if (r < 2) __syncthreads();
     }
   };
-  if (pow2) epilogue(std::true_type{});
-  else epilogue(std::false_type{});
+#ifdef UNFLOW_TUNE_FWD2_NOEPI
+  if (C < 0)
+#endif
+  {
+    if (pow2) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+  }
+#endif   // UNFLOW_FWD2_DIRECT_STORES
+#ifdef UNFLOW_TUNE_FWD2_STAMPS
+  if ((int)blockIdx.x % 61 == 0 && (int)blockIdx.x / 61 < STAMP_SLOTS && (tid & 63) == 0) {
+    unsigned long long *d = g_fwd2_stamps + (((int)blockIdx.x / 61) * 8 + (tid >> 6)) * STAMP_WORDS;
+    d[0] = st_t0; d[1] = st_t1; d[2] = __builtin_amdgcn_s_memtime(); d[3] = st_v; d[4] = st_b; d[5] = st_r0;
+    d[6] = __builtin_amdgcn_s_memrealtime(); d[7] = rowmask | ((unsigned long long)blockIdx.x << 8);
+  }
+#endif
+#ifdef UNFLOW_TUNE_FWD2_NOEPI
+  float sum = 0.f;   // keeps the accumulators alive
+#pragma unroll
+  for (int t = 0; t < NT; ++t) sum += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+  if (sum == 12345.678f) out[0] = sum;
+#endif
 }
 
 constexpr int kMaxDevices = 64;
@@ -211,6 +307,34 @@ int corr_fwd2(const float *in0, const float *in1, float *out, int B, int C, cons
   }
   hipLaunchKernelGGL(corr_fwd2_kernel, dim3(nbx * nby * B * S * 2), dim3(NTHREADS), LDS_BYTES, s, in0, in1, out, C, H, W, nbx, nby);
   return launch_status("correlation_fwd (mfma, instruction blocks)");
+}
+
+}  // namespace unflow
+#ifdef UNFLOW_TUNE_FWD2_STAMPS
+extern "C" int unflow_debug_read_fwd2_stamps(void *dst, size_t bytes) {
+  const size_t n = sizeof(unflow::g_fwd2_stamps) < bytes ? sizeof(unflow::g_fwd2_stamps) : bytes;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(unflow::g_fwd2_stamps), n, 0, hipMemcpyDeviceToHost);
+}
+#endif
+namespace unflow {
+const char *tune_flags_correlation_fwd2() {
+  return ""
+#ifdef UNFLOW_FWD2_GENERATOR_KNOBS
+         " " UNFLOW_FWD2_GENERATOR_KNOBS
+#endif
+#ifdef UNFLOW_TUNE_FWD2_NOSTORE
+         " UNFLOW_TUNE_FWD2_NOSTORE"
+#endif
+#ifdef UNFLOW_TUNE_FWD2_OOBDMA
+         " UNFLOW_TUNE_FWD2_OOBDMA"
+#endif
+#ifdef UNFLOW_TUNE_FWD2_NOEPI
+         " UNFLOW_TUNE_FWD2_NOEPI"
+#endif
+#ifdef UNFLOW_TUNE_FWD2_STAMPS
+         " UNFLOW_TUNE_FWD2_STAMPS"
+#endif
+      ;
 }
 
 }  // namespace unflow
