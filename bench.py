@@ -326,7 +326,7 @@ def cpu_baseline(wl, n_pairs=2, runs=5):
     fbw = wl.flow_bw[:n_pairs].detach().clone().requires_grad_(True)
     got = losses.compute_losses(wl.im1[:n_pairs], wl.im2[:n_pairs], ffw, fbw, border_mask=wl.border[:n_pairs],
                                 mask_occlusion="fb", data_max_distance=3, terms=("ternary", "sym"))
-    rel = {k: abs(float(got[k]) - ls[k]) / abs(ls[k]) for k in ("ternary", "sym")}
+    rel = {k: abs(float(got[k].detach()) - ls[k]) / abs(ls[k]) for k in ("ternary", "sym")}
     if corr_err > 1e-5 or rel["ternary"] > 2e-4 or rel["sym"] > 2e-4:
         raise AssertionError("bench: HIP path and CPU oracle disagree at full size: corr max abs err %.3g, "
                              "loss rel err %s" % (corr_err, rel))
@@ -456,25 +456,39 @@ def kitti_config_step(wl):
     from unflow_amd import graph as ugraph
     from unflow_amd import unsupervised
     torch = wl.torch
-    dev = wl.im1.device
-    g = torch.Generator(device=dev)
-    g.manual_seed(7)
     B = wl.B
-    pf = [(torch.randn((B, H >> (2 + i), W >> (2 + i), 2), device=dev, generator=g) * 0.3).requires_grad_(True)
-          for i in range(5)]
-    pb = [(-f.detach() + 0.02 * torch.randn(f.shape, device=dev, generator=g)).requires_grad_(True) for f in pf]
+    pf, pb = kitti_pyramid_flows(torch, wl.im1.device, B)
 
     def step():
         loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, KITTI)
         return (loss,) + torch.autograd.grad(loss, pf + pb)
     # (the first eager steps also fill the caching allocator with the pyramid's ~180 temporaries: 5 warm-up steps)
     eager_ms = event_time(torch, step, n=10, warm=5)
+    eager = [t.detach().clone() for t in step()]
     gs = ugraph.GraphedStep(step)
     graph_ms = event_time(torch, gs.replay, n=10, warm=2)
+    # the replayed graph computes what the eager step computes: the loss to 1e-6, every level's flow gradients to 1e-6 of
+    # their scale (the same launches in the same order; the scatter-adds flush with float atomics, so not bit for bit).
+    # tests/test_gpu_fullsize.py checks one pair of this step against the oracle.
+    replayed = gs.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, replayed):
+        if not float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()):
+            raise AssertionError("bench: the graph replay of the KITTI pyramid step differs from the eager step")
     return {"note": "NOT the headline: 5-level pyramid loss of the reference's [train_kitti] config "
                     "(ternary + 3*smooth_2nd + 0.2*fb + 12.4*occ, mask_occlusion=fb), fwd+bwd, batch %d" % B,
             "eager_ms": eager_ms, "graph_ms": graph_ms, "pairs_per_s_graph": B / (graph_ms * 1e-3),
-            "loss": float(step()[0].detach())}
+            "loss": float(eager[0]), "graph_matches_eager_to": 1e-6}
+
+
+def kitti_pyramid_flows(torch, dev, B):
+    """The five flow levels (H/4 .. H/64, both directions) of kitti_config_step, seeded."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    pf = [(torch.randn((B, H >> (2 + i), W >> (2 + i), 2), device=dev, generator=g) * 0.3).requires_grad_(True)
+          for i in range(5)]
+    pb = [(-f.detach() + 0.02 * torch.randn(f.shape, device=dev, generator=g)).requires_grad_(True) for f in pf]
+    return pf, pb
 
 
 def traffic_record():
@@ -500,9 +514,10 @@ def traffic_record():
 
 
 # ============================================================================= the other single-GPU configs (informational)
-def run_side_config(args):
-    """BASELINE.json configs[1] (cfg2) and configs[4] (cfg5) as bench lines of their own: same contract, single
-    GPU, never the headline.  cfg2 = SURVEY 8d: B=8, 2 FlowNetC correlation calls (fw and bw direction) on
+def side_config(config, batch, steps, warmup):
+    """BASELINE.json configs[1] (cfg2) and configs[4] (cfg5) as bench records of their own: same contract, single
+    GPU, never the headline (`--config cfg2|cfg5` prints one as a line; the default run attaches both to the headline
+    line as `side_configs`).  cfg2 = SURVEY 8d: B=8, 2 FlowNetC correlation calls (fw and bw direction) on
     [8,256,48,160] + bidirectional backward_warp (2 calls on [8,384,1280,3]); image_warp (what the loss calls)
     is timed beside it.  cfg5 = B=16, 768x1280, fp16 tensors: 2 correlation calls on [16,256,96,160] on the f16
     matrix cores with their 2 backward calls, 2 forward_warp of half flows, 4 full-resolution image_warp of half
@@ -515,8 +530,8 @@ def run_side_config(args):
     gen = torch.Generator(device=dev)
     lrelu = torch.nn.functional.leaky_relu
     global H, W
-    if args.config == "cfg2":
-        B = 8 if args.batch == 32 else args.batch
+    if config == "cfg2":
+        B = 8 if batch == 32 else batch
         gen.manual_seed(1234 + 2)
         fa = lrelu(torch.randn((B, FEAT_C, H8, W8), device=dev, generator=gen), 0.1)
         fb = lrelu(torch.randn((B, FEAT_C, H8, W8), device=dev, generator=gen), 0.1)
@@ -538,7 +553,7 @@ def run_side_config(args):
                "image_warp": (0, 2 * B * H * W * 32)}
         peak_tf = FP32_MATRIX_PEAK_TF
     else:
-        B = 16 if args.batch == 32 else args.batch
+        B = 16 if batch == 32 else batch
         hh, ww = 768, 1280
         h8, w8 = hh // 8, ww // 8
         gen.manual_seed(1234 + 5)
@@ -570,11 +585,11 @@ def run_side_config(args):
                "corr_bwd": (4 * fl * B, 2 * 2 * h8 * w8 * (D + 4 * FEAT_C) * B),
                "forward_warp": (0, 2 * B * hh * ww * 8), "image_warp": (0, 4 * B * hh * ww * 16)}
         peak_tf = F16_MATRIX_PEAK_TF
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -590,9 +605,9 @@ def run_side_config(args):
     # these kernels are priced against BOTH ceilings: on the f16 matrix cores the correlation's algorithmic
     # traffic at 8 TB/s takes longer than its flops at the dense f16 peak, so cfg5 is HBM-bound
     hbm_bound = per[dom]["frac_of_8TBs"] > per[dom].get("frac_of_matrix_peak", 0.0)
-    out = {"metric": "image-pairs/sec, BASELINE %s (informational; the headline is cfg3)" % args.config,
-           "value": B * args.steps / dt, "unit": "image-pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    out = {"metric": "image-pairs/sec, BASELINE %s (informational; the headline is cfg3)" % config,
+           "value": B * steps / dt, "unit": "image-pairs/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": dtype, "data": "synthetic", "informational": True,
            "config": {"workload": work, "global_batch": B, "height": hh, "width": ww, "parallelism": "single GPU"},
            "roofline": {"bound": "hbm" if hbm_bound else "mfma", "kernel": dom + " (both calls of the step)",
@@ -601,7 +616,11 @@ def run_side_config(args):
                         "frac": per[dom]["frac_of_8TBs"] if hbm_bound else per[dom]["frac_of_matrix_peak"],
                         "traffic": None, "frac_basis": "HIP events around the calls on the launch stream; algorithmic bytes / flops of SURVEY 8d",
                         "parts": per}}
-    print(json.dumps(out))
+    return out
+
+
+def run_side_config(args):
+    print(json.dumps(side_config(args.config, args.batch, args.steps, args.warmup)))
     return 0
 
 
@@ -778,6 +797,17 @@ def main():
             out["kitti_config_step"] = kitti_config_step(wl)
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: the other ranks would idle at the barrier
             out["cpu_baseline"] = cpu_baseline(wl, runs=args.cpu_runs)
+        if not args.no_extras and world == 1 and args.batch == 32:
+            # BASELINE configs[1] and configs[4], timed after the headline's region (a few seconds): the driver's record
+            # carries them; `value` above stays cfg3
+            del wl
+            torch.cuda.empty_cache()
+            out["side_configs"] = {}
+            for cfg in ("cfg2", "cfg5"):
+                sc = side_config(cfg, 32, args.steps, args.warmup)
+                out["side_configs"][cfg] = {"workload": sc["config"]["workload"], "value": sc["value"], "unit": sc["unit"],
+                                            "ms_per_step": sc["ms_per_step"], "dtype": sc["dtype"], "roofline": sc["roofline"]}
+                torch.cuda.empty_cache()
         print(json.dumps(out))
         sys.stdout.flush()
     if world > 1:

@@ -137,12 +137,14 @@ size_t unflow_reduce_workspace_floats(int B, int H, int W);
  * write *loss: they append (workspace, number of partial sums, 1 / norm) to the caller-owned plan.
  * unflow_reduce_plan_run then reduces all segments in ONE launch (one block each, the same fixed order and double
  * accumulation as the immediate form: results[i] is bit-identical) and folds them in a second one-block launch:
- *   total = sum_i coeff[i] * results[i],   per_term[t] = sum_{i: term[i] == t} term_weight[i] * results[i]  (t < 8).
+ *   total = sum_i coeff[i] * results[i],   per_term[t] = sum_{i: term[i] == t} term_weight[i] * results[i]  (t < UNFLOW_PLAN_TERMS; a larger term[i] is an error,
+ * a negative one belongs to no term).
  * coeff / term / term_weight are HOST arrays of plan->n entries (copied into the kernel arguments); results
- * (plan->n floats), total (1) and per_term (8) are device buffers.  At most UNFLOW_PLAN_CAPACITY segments; the
+ * (plan->n floats), total (1) and per_term (UNFLOW_PLAN_TERMS) are device buffers.  At most UNFLOW_PLAN_CAPACITY segments; the
  * workspaces must stay untouched until the run.  The plan is plain data: it can be built once while a HIP graph is
  * captured and is not needed for replays. */
 #define UNFLOW_PLAN_CAPACITY 128
+#define UNFLOW_PLAN_TERMS 8      /* per_term holds this many floats */
 typedef struct {
   int n;
   const float *partial[UNFLOW_PLAN_CAPACITY];

@@ -296,6 +296,33 @@ def test_bench_loss_leg_cfg3(oracle_mod, dev):
         np.testing.assert_allclose(got_g.cpu().numpy(), want_g, rtol=1e-5, atol=1e-5 * np.abs(want_g).max())
 
 
+def test_bench_kitti_pyramid_step_full_size_vs_oracle(oracle_mod, dev):
+    """bench.py's `kitti_config_step` at the size it is timed at (384x1280; core/unsupervised.py:85-145 with
+    config_template/config.ini:123,166-174's mix): one pair of that step -- the same images, border mask and
+    five-level flow pyramid -- against oracle.pyramid_loss / pyramid_loss_grad: combined loss and every term 1e-5,
+    every level's flow gradients (both directions) 1e-5 of their scale.  A few seconds of CPU."""
+    import bench
+    from unflow_amd import unsupervised
+    B, pair = 2, 1
+    wl = bench.Workload(B, dev, seed=1234, global_batch=B, features=False)
+    pf, pb = bench.kitti_pyramid_flows(torch, dev, B)
+    sl = slice(pair, pair + 1)
+    tf_ = [f.detach()[sl].clone().requires_grad_(True) for f in pf]
+    tb_ = [f.detach()[sl].clone().requires_grad_(True) for f in pb]
+    got, got_terms = unsupervised.pyramid_loss(wl.im1[sl], wl.im2[sl], wl.border[sl], tf_, tb_, bench.KITTI)
+    got.backward()
+    host = lambda t: t.detach().cpu().numpy()
+    args = (host(wl.im1[sl]), host(wl.im2[sl]), host(wl.border[sl]), [host(f) for f in tf_], [host(f) for f in tb_], dict(bench.KITTI))
+    want, want_terms = oracle_mod.pyramid_loss(*args)
+    np.testing.assert_allclose(float(got.detach()), want, rtol=1e-5)
+    for k in ("ternary", "smooth_2nd", "fb", "occ"):
+        np.testing.assert_allclose(float(got_terms[k]), want_terms[k], rtol=1e-5, atol=1e-12, err_msg=k)
+    want_fw, want_bw = oracle_mod.pyramid_loss_grad(*args)
+    for i in range(5):
+        for t, w in ((tf_[i], want_fw[i]), (tb_[i], want_bw[i])):
+            assert np.abs(host(t.grad) - w).max() <= 1e-5 * np.abs(w).max(), "level %d" % i
+
+
 def test_batch_shards_sum_to_whole_batch_cfg3(dev):
     """The N-GPU partition on one device: compute_losses on contiguous batch shards with
     norm_batch = global batch sums to the whole-batch losses, and each shard's flow gradients are
@@ -314,7 +341,7 @@ def test_batch_shards_sum_to_whole_batch_cfg3(dev):
         ls = losses.compute_losses(wl.im1[sl], wl.im2[sl], ffw, fbw, border_mask=wl.border[sl], mask_occlusion="fb",
                                    data_max_distance=3, norm_batch=norm_batch, terms=terms)
         (ls["ternary"] + 3.0 * ls["smooth_2nd"] + 0.2 * ls["fb"] + 12.4 * ls["occ"]).backward()
-        return {k: float(v) for k, v in ls.items()}, ffw.grad, fbw.grad
+        return {k: float(v.detach()) for k, v in ls.items()}, ffw.grad, fbw.grad
     whole, g_fw, g_bw = run(slice(0, B), 0)
     total = {k: 0.0 for k in terms}
     for r in range(world):

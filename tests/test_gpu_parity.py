@@ -1097,13 +1097,42 @@ def test_deferred_reductions_match_immediate(dev):
     np.testing.assert_allclose(float(total), sum(c * w for c, w in zip(coeff, want)), rtol=1e-6)
     for t in range(8):
         np.testing.assert_allclose(float(per_term[t]), sum(2.0 * w for i, w in enumerate(want) if i % 8 == t), rtol=1e-6)
-    assert losses.DeferredReductions.active is None
+    assert losses.DeferredReductions.current() is None
     assert float(losses.charbonnier_loss(tim1 - tim2, mask, beta=255)) == want[3]        # the immediate form is back
     with pytest.raises(RuntimeError, match="nest"):
         with losses.DeferredReductions(dev):
             with losses.DeferredReductions(dev):
                 pass
-    assert losses.DeferredReductions.active is None
+    assert losses.DeferredReductions.current() is None
+
+
+def test_deferred_reductions_are_per_thread_and_a_null_scalar_is_an_error(dev):
+    """The C plan is thread_local and so is the Python context: a loss forward on ANOTHER thread while a deferred block
+    is open runs in immediate mode (its own scalar, right away), and the C entry points refuse a NULL output scalar when
+    no plan is open on the calling thread instead of writing through it."""
+    import threading
+    from unflow_amd import _lib, losses
+    from unflow_amd.losses import _ptr, _stream, _workspace
+    x = torch.rand((1, 8, 8, 2), device=dev)
+    want = float(losses.charbonnier_loss(x))
+    seen = {}
+
+    def other():
+        with torch.cuda.device(dev):
+            seen["current"] = losses.DeferredReductions.current()
+            seen["value"] = float(losses.charbonnier_loss(x))
+    with losses.DeferredReductions(dev) as d:
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert d.plan.n == 0                                   # nothing of the other thread landed in this plan
+    assert seen["current"] is None and seen["value"] == want
+    ws = _workspace(1, 8, 8, dev)
+    with torch.cuda.device(dev):
+        rc = _lib.load().unflow_charbonnier_fwd(_ptr(x), None, 0, None, _ptr(ws), 1, 8, 8, 2, 0.45, 1.0, 0.001, 0.0, 0, _stream())
+    assert rc == _lib.UNFLOW_ERR_INVALID_ARGUMENT
+    assert b"NULL" in _lib.load().unflow_last_error()
+    torch.cuda.synchronize()
 
 
 def test_fan_out_sums_the_consumers_gradients_in_one_launch(dev):

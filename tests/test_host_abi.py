@@ -134,17 +134,69 @@ def test_matrix_kernels_keep_their_accumulators_in_registers(tmp_path):
     assert b4 == [(256, 0), (256, 0)], b4
 
 
-def test_the_instruction_blocks_are_what_the_generator_writes(tmp_path):
-    """unflow_amd/csrc/corr_bwd4_asm.inc is generated (tools/gen_corr_bwd4_asm.py) and committed: the two must agree."""
+@pytest.mark.parametrize("gen_name,inc_name", [("gen_corr_bwd4_asm.py", "corr_bwd4_asm.inc"), ("gen_corr_fwd_asm.py", "corr_fwd2_asm.inc")])
+def test_the_instruction_blocks_are_what_the_generator_writes(tmp_path, gen_name, inc_name):
+    """unflow_amd/csrc/corr_bwd4_asm.inc and corr_fwd2_asm.inc are generated (tools/gen_corr_*_asm.py, no knob set) and
+    committed: generator and include must agree."""
     import shutil
-    gen = os.path.join(ROOT, "tools", "gen_corr_bwd4_asm.py")
-    inc = os.path.join(ROOT, "unflow_amd", "csrc", "corr_bwd4_asm.inc")
+    gen = os.path.join(ROOT, "tools", gen_name)
+    inc = os.path.join(ROOT, "unflow_amd", "csrc", inc_name)
     work = tmp_path / "repo"
     (work / "tools").mkdir(parents=True)
     (work / "unflow_amd" / "csrc").mkdir(parents=True)
-    shutil.copy(gen, work / "tools" / "gen_corr_bwd4_asm.py")
-    subprocess.run([sys.executable, str(work / "tools" / "gen_corr_bwd4_asm.py")], check=True, capture_output=True)
-    assert open(work / "unflow_amd" / "csrc" / "corr_bwd4_asm.inc").read() == open(inc).read()
+    shutil.copy(gen, work / "tools" / gen_name)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("FWD2_")}
+    subprocess.run([sys.executable, str(work / "tools" / gen_name)], check=True, capture_output=True, env=env)
+    assert open(work / "unflow_amd" / "csrc" / inc_name).read() == open(inc).read()
+
+
+def test_forward_instruction_stream_kernel_resources_and_m0_discipline(tmp_path):
+    """corr_fwd2_kernel keeps accumulators and fragments in fixed registers behind one asm statement: the compiler must
+    come out at 128 VGPRs (two workgroups per CU) with nothing in scratch.  And in both TUs with hand-written blocks
+    every LDS-DMA instruction -- the blocks' own and the compiler's -- has its write of M0 in its own stretch of code
+    (tools/check_store_hazard.py scan_m0: the blocks write M0 and the compiler does not model that)."""
+    import importlib.util
+    import re
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(ROOT, "tools", "check_store_hazard.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    total = 0
+    for tu in ("correlation_fwd2", "correlation_mfma"):
+        src = os.path.join(ROOT, "unflow_amd", "csrc", tu + ".hip")
+        lst = str(tmp_path / (tu + ".s"))
+        out = subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-Wno-pass-failed", "-Wno-inline-asm",
+                              "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-S", "-o", lst, src],
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        found, n = chk.scan_m0(open(lst).read().split("\n"), tu)
+        assert found == [], "\n".join(found)
+        total += n
+        if tu == "correlation_fwd2":
+            names = re.findall(r"Function Name: (\S+)", out.stderr)
+            vgprs = [int(v) for v in re.findall(r" VGPRs: (\d+)", out.stderr)]
+            scratch = [int(v) for v in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+            assert [(v, s) for nm, v, s in zip(names, vgprs, scratch) if "corr_fwd2_kernel" in nm] == [(128, 0)], list(zip(names, vgprs, scratch))
+    assert total > 100          # the scan saw the LDS-DMA instructions
+
+
+def test_m0_scanner_flags_a_dma_behind_a_foreign_block():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(ROOT, "tools", "check_store_hazard.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    ok = ["_Zk:", "\ts_mov_b32 m0, s4", "\tv_add_u32 v1, v2, v3", "\tbuffer_load_dwordx4 v1, s[4:7], 0 offen lds",
+          "\t;;#ASMSTART", "\ts_add_u32 m0, s9, 16", "\ts_nop 0", "\tbuffer_load_dwordx4 v2, s[4:7], s3 offen lds", "\t;;#ASMEND"]
+    assert chk.scan_m0(ok, "t") == ([], 2)
+    bad = ["_Zk:", "\ts_mov_b32 m0, s4", "\t;;#ASMSTART", "\ts_add_u32 m0, s9, 16", "\tbuffer_load_dwordx4 v2, s[4:7], s3 offen lds", "\t;;#ASMEND",
+           "\tbuffer_load_dwordx4 v1, s[4:7], 0 offen lds"]
+    found, n = chk.scan_m0(bad, "t")
+    assert n == 2 and len(found) == 1 and "end of an asm block" in found[0]
+    loop = ["_Zk:", "\ts_mov_b32 m0, s4", ".LBB0_1:", "\tbuffer_load_dword v1, s[4:7], 0 offen lds"]
+    assert len(chk.scan_m0(loop, "t")[0]) == 1
 
 
 def test_the_shipped_library_is_not_a_diagnostic_build():

@@ -93,6 +93,54 @@ def scan(lines, name):
     return found
 
 
+LDS_DMA = re.compile(r"^\s*(buffer_load_dword\w*\s.*\blds\b|global_load_lds_\w+)")
+M0_WRITE = re.compile(r"^\s*s_\w+\s+m0\b")
+
+
+def scan_m0(lines, name):
+    """For COMPILER LISTINGS (hipcc -S: they carry the ;;#ASMSTART / ;;#ASMEND markers).  Every LDS-DMA instruction
+    takes its LDS destination from M0.  The hand-written instruction blocks write M0 themselves in front of each of
+    theirs, and the compiler does not model that (an "m0" clobber only draws a warning: the register is reserved), so
+    a compiler-issued LDS-DMA that relied on an M0 value from BEFORE such a block would land in the wrong place.  The
+    invariant that rules it out: walking back from every LDS-DMA instruction, the nearest write of M0 comes before any
+    label and on the same side of the asm markers (a block's DMA: inside the same block; the compiler's: no block in
+    between).  Returns (findings, number of LDS-DMA instructions)."""
+    found, kern, code = [], "?", []        # (kernel, kind, text): kind = "i" instruction, "l" label, "s" ASMSTART, "e" ASMEND
+    for raw in lines:
+        t = raw.strip()
+        if t.startswith(";;#ASMSTART"):
+            code.append((kern, "s", t))
+        elif t.startswith(";;#ASMEND"):
+            code.append((kern, "e", t))
+        elif re.match(r"^[\w.$]+:", t):
+            m = re.match(r"^(_Z\w+):", t)
+            if m:
+                kern = m.group(1)
+            if not re.match(r"^\d+:", t):          # numeric local labels belong to the blocks themselves
+                code.append((kern, "l", t))
+        elif not t or t.startswith((";", ".", "//")):
+            continue
+        else:
+            code.append((kern, "i", t.split(";")[0].strip()))
+    n = 0
+    for i, (kern, kind, s) in enumerate(code):
+        if kind != "i" or not LDS_DMA.match(s):
+            continue
+        n += 1
+        j, why = i - 1, None
+        while j >= 0:
+            k, t = code[j][1], code[j][2]
+            if k == "i" and M0_WRITE.match(t):
+                break
+            if k in ("l", "s", "e"):
+                why = {"l": "a label", "s": "the start of an asm block", "e": "the end of an asm block"}[k]
+                break
+            j -= 1
+        if why or j < 0:
+            found.append("%s [%s]: %s   <- %s between it and the nearest write of m0" % (name, kern[:80], s, why or "nothing"))
+    return found, n
+
+
 def device_listings(so):
     tmp = tempfile.mkdtemp(prefix="unflow_disasm_")
     try:
@@ -107,25 +155,35 @@ def device_listings(so):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def check(paths):
+def check(paths, m0=None):
+    """m0: a list that receives [findings, number of LDS-DMA instructions] of scan_m0."""
     found, n_stores = [], 0
+    m0_found, n_dma = [], 0
     for p in paths:
         if p.endswith(".so") or p.endswith(".o") or p.endswith(".co"):
-            for name, lines in device_listings(p):
-                n_stores += sum(1 for l in lines if STORE.match(l.split("//")[0]))
-                found += scan(lines, name)
+            listings = device_listings(p)
         else:
-            lines = open(p).read().split("\n")
-            n_stores += sum(1 for l in lines if STORE.match(l))
-            found += scan(lines, os.path.basename(p))
+            listings = [(os.path.basename(p), open(p).read().split("\n"))]
+        for name, lines in listings:
+            n_stores += sum(1 for l in lines if STORE.match(l.split("//")[0]))
+            found += scan(lines, name)
+            if p.endswith(".s"):
+                f, n = scan_m0(lines, name)
+                m0_found += f
+                n_dma += n
+    if m0 is not None:
+        m0[:] = [m0_found, n_dma]
     return found, n_stores
 
 
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     paths = sys.argv[1:] or [os.path.join(root, "unflow_amd", "libunflow_hip.so")]
-    found, n = check(paths)
-    for f in found:
+    m0 = []
+    found, n = check(paths, m0)
+    for f in found + m0[0]:
         print(f)
-    print("%d wide VMEM stores scanned, %d with a data register overwritten within %d instructions" % (n, len(found), WINDOW))
-    sys.exit(1 if found else 0)
+    print("%d wide VMEM stores scanned, %d with a data register overwritten within %d wait states" % (n, len(found), WINDOW))
+    if m0[1]:
+        print("%d LDS-DMA instructions scanned, %d whose m0 is not written in their own stretch of code" % (m0[1], len(m0[0])))
+    sys.exit(1 if found or m0[0] else 0)

@@ -81,6 +81,7 @@ SIGNATURES = {
 }
 
 PLAN_CAPACITY = 128   # UNFLOW_PLAN_CAPACITY
+PLAN_TERMS = 8        # UNFLOW_PLAN_TERMS: floats of the per-term buffer of unflow_reduce_plan_run
 
 
 class ReducePlan(ctypes.Structure):

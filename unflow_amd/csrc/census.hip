@@ -829,12 +829,16 @@ int reduce_partials(const float *partial, int n, double inv_norm, float *loss, h
     t_plan->inv_norm[i] = inv_norm;
     return UNFLOW_OK;
   }
+  // (a NULL scalar is the deferred mode's calling convention: without an open plan on THIS thread it would be
+  // written through)
+  if (!loss) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "loss: the output scalar is NULL and no reduce plan is open on this thread");
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(1024), 0, s, partial, n, inv_norm, loss);
   return launch_status("reduce_partials");
 }
 
 int zero_loss(float *loss, const char *what, hipStream_t s) {
   if (t_plan) return reduce_partials(nullptr, 0, 0.0, loss, s);
+  if (!loss) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "%s: the output scalar is NULL and no reduce plan is open on this thread", what);
   if (hipMemsetAsync(loss, 0, sizeof(float), s) != hipSuccess) return launch_status(what);
   return UNFLOW_OK;
 }
@@ -872,7 +876,7 @@ __global__ __launch_bounds__(64) void fold_results_kernel(FoldArgs a, int n, con
     float s = 0.f;
     for (int i = 0; i < n; ++i) s = fmaf(a.coeff[i], results[i], s);
     *total = s;
-  } else if (t <= 8 && per_term) {
+  } else if (t <= UNFLOW_PLAN_TERMS && per_term) {
     float s = 0.f;
     for (int i = 0; i < n; ++i)
       if (a.term[i] == t - 1) s = fmaf(a.term_weight[i], results[i], s);
@@ -924,6 +928,10 @@ extern "C" int unflow_reduce_plan_run(const unflow_reduce_plan *plan, const floa
     return fail(UNFLOW_ERR_INVALID_ARGUMENT, "reduce plan: invalid plan or NULL buffer");
   hipStream_t s = as_stream(stream);
   const int n = plan->n;
+  if (term)
+    for (int i = 0; i < n; ++i)
+      if (term[i] >= UNFLOW_PLAN_TERMS)
+        return fail(UNFLOW_ERR_INVALID_ARGUMENT, "reduce plan: term %d of segment %d (per_term holds %d sums)", term[i], i, UNFLOW_PLAN_TERMS);
   if (n > 0) {
     PlanArgs pa;
     for (int i = 0; i < UNFLOW_PLAN_CAPACITY; ++i) {

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
                  : [aaddr] "v"(aaddr), [baddr] "v"(baddr), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]),
                    [v3] "v"(voff[3]), [v4] "v"(voff[4]), [r0] "s"(r0), [r1] "s"(r1), [mask] "s"(rowmask), [m1] "s"(m1),
                    [m0f] "s"(m0f), [cstep] "s"(cstep), [npairs] "s"(npairs)
-                 : UNFLOW_FWD2_FRAG_CLOBBERS, "scc", "memory" UNFLOW_FWD2_STAMP_CLOBBERS);
+                 : UNFLOW_FWD2_FRAG_CLOBBERS, "scc", "m0", "memory" UNFLOW_FWD2_STAMP_CLOBBERS);
 #ifdef UNFLOW_TUNE_FWD2_STAMPS
     st_t1 = __builtin_amdgcn_s_memtime();
     st_v = accv;

@@ -1498,7 +1498,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
                          [fetch] "s"(fetch_), [amask] "s"(amask), [a_m0] "s"(a_m0), [asoff] "s"(asoff), [rin] "s"(rin),
                          [av0] "v"(av0), [av1] "v"(av1), [av2] "v"(av2), [av3] "v"(av3),
                          [t_m0] "s"(t_m0), [twoff] "s"(twoff), [rtop] "s"(rtop), [tb0] "v"(tb0), [tb1] "v"(tb1)
-                     : "memory", "scc", "vcc", UNFLOW_BWD4_CLOBBERS);   // (and m0, which the compiler sets anew in front of every use of its own)
+                     : "memory", "scc", "vcc", "m0", UNFLOW_BWD4_CLOBBERS);   // (m0: the blocks write it in front of every LDS-DMA)
       };
       auto kstep_dma1 = [&]() __attribute__((always_inline)) {
         constexpr int ia = 4 * S * 2 * 4;
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         asm volatile(UNFLOW_BWD4_KSTEP1_DMA
                      : : [live] "s"(live_), [a_rd] "v"(a_rd), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [ia] "i"(ia), [ib] "i"(ib),
                          [fetch] "s"(fetch_), [t3] "s"(t3), [t_m0] "s"(t_m0), [twoff] "s"(twoff), [rtop] "s"(rtop), [tb2] "v"(tb2), [tb3] "v"(tb3)
-                     : "memory", "scc", UNFLOW_BWD4_CLOBBERS);
+                     : "memory", "scc", "m0", UNFLOW_BWD4_CLOBBERS);
       };
       // K-steps 3, 4: the pending tile store goes LAST among the vector-memory operations in front of the barrier
       // (behind the DMA), so that the barrier can wait for the DMA without the stores

@@ -9,6 +9,19 @@ executor running a static graph; this is its MI355X counterpart.
 """
 import torch
 
+# torch exposes a setter but no getter for this flag (default: on); GraphedStep switches the warning off only while it
+# captures and puts back what the process last set THROUGH set_accumulate_grad_stream_warning() below (True if never).
+_warn_stream_mismatch = True
+
+
+def set_accumulate_grad_stream_warning(on):
+    """Process-wide: autograd's warning about gradient accumulation across streams (what GraphedStep restores)."""
+    global _warn_stream_mismatch
+    _warn_stream_mismatch = bool(on)
+    setter = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    if setter is not None:
+        setter(_warn_stream_mismatch)
+
 
 def _detached(x):
     if isinstance(x, torch.Tensor):
@@ -48,7 +61,7 @@ class GraphedStep:
             self.outputs = _detached(out)
         finally:
             if quiet is not None:
-                quiet(True)
+                quiet(_warn_stream_mismatch)
 
     def replay(self):
         self.graph.replay()

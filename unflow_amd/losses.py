@@ -11,6 +11,7 @@ no caller anywhere in the reference and are not mirrored.
 """
 import ctypes
 import math
+import threading
 
 import torch
 
@@ -35,7 +36,11 @@ class DeferredReductions:
     The loss pyramid of the reference (core/unsupervised.py:114-141) evaluates ~40 scalars per step: ~40 launches
     become 2.  The C side is ``unflow_reduce_plan_*`` (include/unflow_hip.h); the plan is per thread."""
 
-    active = None
+    _tls = threading.local()        # the C plan is per thread (thread_local in census.hip): so is the open context
+
+    @classmethod
+    def current(cls):
+        return getattr(cls._tls, "active", None)
 
     def __init__(self, device):
         self.plan = _lib.ReducePlan()
@@ -43,14 +48,14 @@ class DeferredReductions:
         self.keep = []              # the workspaces must live until fold()
 
     def __enter__(self):
-        if DeferredReductions.active is not None:
+        if DeferredReductions.current() is not None:
             raise RuntimeError("DeferredReductions does not nest")
         _lib.check(_lib.load().unflow_reduce_plan_begin(ctypes.byref(self.plan)))
-        DeferredReductions.active = self
+        DeferredReductions._tls.active = self
         return self
 
     def __exit__(self, *exc):
-        DeferredReductions.active = None
+        DeferredReductions._tls.active = None
         _lib.load().unflow_reduce_plan_end()
         return False
 
@@ -72,11 +77,11 @@ class DeferredReductions:
 
 def _loss_out(device):
     """The scalar a loss forward writes -- None (NULL: not written) while reductions are deferred."""
-    return None if DeferredReductions.active is not None else torch.empty((), device=device, dtype=torch.float32)
+    return None if DeferredReductions.current() is not None else torch.empty((), device=device, dtype=torch.float32)
 
 
 def _loss_result(loss, ws):
-    d = DeferredReductions.active
+    d = DeferredReductions.current()
     return loss if d is None else d.last(ws)
 
 

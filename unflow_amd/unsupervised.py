@@ -9,11 +9,13 @@ passes the pyramid in and adds its own regularisation loss.
 """
 import torch
 
+from . import _lib
 from .losses import DeferredReductions, compute_losses_parts
 from .util import downsample
 
 # unsupervised.py:10
 LOSSES = ['occ', 'sym', 'fb', 'grad', 'ternary', 'photo', 'smooth_1st', 'smooth_2nd']
+assert len(LOSSES) <= _lib.PLAN_TERMS      # one per-term sum of unflow_reduce_plan_run each
 FLOW_SCALE = 5.0  # core/flownet.py:11
 
 
@@ -104,7 +106,7 @@ class _Fold(torch.autograd.Function):
             term[slot] = LOSSES.index(name)
             term_w[slot] = float(layer_weight)
         total = torch.empty((), device=deferred.results.device, dtype=torch.float32)
-        sums = torch.empty(len(LOSSES), device=total.device, dtype=torch.float32)
+        sums = torch.empty(_lib.PLAN_TERMS, device=total.device, dtype=torch.float32)   # (the kernel writes all of them)
         deferred.fold(coeff, term, term_w, total, sums)
         ctx.coeff_t = _coeff_tensor(total.device, tuple(float(c) for c in coeffs))
         ctx.mark_non_differentiable(sums)
