@@ -102,6 +102,14 @@ def test_bench_gpus_flag_spawns_ranks():
     assert out3.returncode == 0 and lines3[0]["n_gpus"] == 3
 
 
+def test_bench_eight_rank_launch_path_dry():
+    """The driver's scaling run ends at `--gpus 8`: the 8-rank launch, rendezvous on 127.0.0.1 and all-reduce are
+    rehearsed here (gloo, --dry: no GPU work), both self-spawned and under torch.distributed.run's environment."""
+    out, lines = _run_bench("--gpus", "8", "--backend", "gloo", "--dry")
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["allreduce_check"] == 36.0      # 1 + 2 + ... + 8
+
+
 def test_bench_under_a_launcher_takes_ranks_from_env():
     """Under torch.distributed.run (WORLD_SIZE set) bench.py does not spawn: one process, one rank."""
     out, lines = _run_bench("--gpus", "2", "--dry", env_extra=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))

@@ -57,17 +57,34 @@ def dma_t(j):
             "buffer_load_dwordx4 v%d, %%[rtop], 0 offen lds" % tv]
 
 
+SPREAD = os.environ.get("B4_SPREAD", "1") != "0"   # the next K-step's fragment reads one per MFMA gap (0: in one clump)
+
+
 def kstep(p, dma=None):
     """dma None: plain; 'A': K-step 0 of a row (the four A pieces and top pieces 0, 1 of the NEXT row's stage);
-    'T': K-step 1 (top pieces 2, 3).  [fetch] = 0 skips them (last row of the last item)."""
+    'T': K-step 1 (top pieces 2, 3).  [fetch] = 0 skips them (last row of the last item).
+    The 11 fragment reads of the next K-step go ONE PER MFMA GAP into slot 0's group (the eight A reads) and slot 1's
+    (the three B reads): a wave that runs alone on its SIMD -- its partner waits at the row barrier for about half
+    of every row -- hides at most ~5 single-issue instructions behind an MFMA, and a clump of 11 LDS instructions
+    behind the first group left the matrix pipe idle.  A dead slot's group is skipped as a whole; its share of the
+    reads is then issued in the skip path."""
     n = 1 - p
     L = ["s_waitcnt lgkmcnt(0)"]
+    rd = reads(n)
+    share = {0: rd[:MTS], 1: rd[MTS:], 2: []} if SPREAD else {0: [], 1: [], 2: []}
     for sl in range(RING):
+        mm = mfmas(p, sl)
         L += ["s_bitcmp0_b32 %%[live], %d" % sl, "s_cbranch_scc1 %df" % (sl + 1)]
-        L += mfmas(p, sl)
-        L += ["%d:" % (sl + 1)]
-        if sl == 0:
-            L += reads(n)
+        if share[sl]:
+            for i, m in enumerate(mm):
+                L.append(m)
+                if i < len(share[sl]):
+                    L.append(share[sl][i])
+            L += ["s_branch %df" % (sl + 4), "%d:" % (sl + 1)] + share[sl] + ["%d:" % (sl + 4)]
+        else:
+            L += mm + ["%d:" % (sl + 1)]
+        if sl == 0 and not SPREAD:
+            L += rd
         # (every group is guarded on its own and leaves EXEC complete: the MFMAs that follow need all lanes)
         if dma == "A":
             if sl == 0:       # lanes that take part in an A piece: the same mask for the wave's four pieces
