@@ -409,7 +409,9 @@ def loss_kernels_roofline(wl, copy_gbs):
     npx = B * H * W
     ffw, fbw = wl.flow_fw.detach(), wl.flow_bw.detach()
     pmc = {}
-    path = os.path.join(ROOT, "profiles", "r03_pmc_loss.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_loss.json")      # (the loss kernels are round 3's: either round's counters)
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r03_pmc_loss.json")
     if os.path.exists(path):
         with open(path) as fh:
             pmc = json.load(fh)
@@ -427,7 +429,7 @@ def loss_kernels_roofline(wl, copy_gbs):
         rec = pmc.get(key, {})
         ipw = rec.get("valu_insts_per_wave")
         row = {"ms": ms, "bound": "valu issue", "pmc_valu_issue_frac": rec.get("valu_issue_frac"),
-               "pmc_source": "profiles/r03_pmc_loss.json" if rec else None}
+               "pmc_source": os.path.relpath(path, ROOT) if rec else None}
         if ipw:
             trans = 19 * 24 * 3
             floor_ms = rec["waves"] * ((ipw - trans) * 4 + trans * 8) / 1024 / clock * 1e3 * (B / 32.0)
@@ -491,25 +493,37 @@ def kitti_pyramid_flows(torch, dev, B):
     return pf, pb
 
 
+TRAFFIC_FILE = "profiles/r04_traffic.json"
+KERNEL_SOURCES = ("correlation_bwd4.hip", "corr_bwd4_asm.inc", "correlation_fwd2.hip", "corr_fwd2_asm.inc", "corr_mfma_common.h")
+
+
+def correlation_kernel_source_sha16():
+    """Hash of the sources of the shipped float32 correlation kernels (forward and backward, with their generated
+    instruction blocks): a traffic record is only valid for the source it was collected on."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        path = os.path.join(ROOT, "unflow_amd", "csrc", name)
+        h.update(open(path, "rb").read() if os.path.exists(path) else b"?")
+    return h.hexdigest()[:16]
+
+
 def traffic_record():
     """HBM bytes of the dominant kernel from PMC counters.  bench.py cannot sit under
     ``rocprofv3 --pmc`` and time itself, so the counters come from a separate pass
-    (tools/profile_round.sh -> profiles/r03_traffic.json); the record carries the hash of the
+    (tools/profile_round.sh -> profiles/r04_traffic.json); the record carries the hash of the
     kernel source it was collected on and is only used when that is the source of this build."""
-    path = os.path.join(ROOT, "profiles", "r03_traffic.json")
-    src = os.path.join(ROOT, "unflow_amd", "csrc", "correlation_mfma.hip")
-    if not (os.path.exists(path) and os.path.exists(src)):
+    path = os.path.join(ROOT, TRAFFIC_FILE)
+    if not os.path.exists(path):
         return None, None
     with open(path) as fh:
         rec = json.load(fh)
-    inc = os.path.join(os.path.dirname(src), "corr_bwd4_asm.inc")      # the backward's instruction blocks are kernel source too
-    sha = hashlib.sha256(open(src, "rb").read() + (open(inc, "rb").read() if os.path.exists(inc) else b"")).hexdigest()[:16]
+    sha = correlation_kernel_source_sha16()
     if rec.get("kernel_source_sha16") != sha:
-        return None, {"file": "profiles/r03_traffic.json", "stale": True,
-                      "note": "collected on another version of correlation_mfma.hip: not reported"}
+        return None, {"file": TRAFFIC_FILE, "stale": True,
+                      "note": "collected on another version of the correlation kernels' source: not reported"}
     return rec["corr_bwd_both_launches"]["hbm_bytes"], {
-        "file": "profiles/r03_traffic.json", "kernel_source_sha16": sha,
-        "how": "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/traffic_pmc.sh), FETCH_SIZE doubled "
+        "file": TRAFFIC_FILE, "kernel_source_sha16": sha,
+        "how": "offline rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/profile_round.sh), FETCH_SIZE doubled "
                "(gfx950), per call = both gradient launches; not measured in this run"}
 
 
@@ -764,7 +778,7 @@ def main():
                          "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP32_MATRIX_PEAK_TF,
                          "frac_basis": "HIP events around the call on the launch stream, mean over the timed region "
-                                       "(rocprofv3 kernel averages of the same command: profiles/r03_bench_kernel_stats.csv)",
+                                       "(rocprofv3 kernel averages of the same command: profiles/r04_bench_kernel_stats.csv)",
                          "traffic": traffic, "traffic_source": traffic_src,
                          "stream_copy_gbs": copy_gbs,
                          "avg_launch_ms": bwd_ms,

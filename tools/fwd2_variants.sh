@@ -13,7 +13,7 @@ while [ $# -gt 2 ]; do
   env $knobs FWD2_OUT=$inc python ../../tools/gen_corr_fwd_asm.py >/dev/null
   $HIPCC $FLAGS $extra -DUNFLOW_FWD2_INC="\"$inc\"" -c -o ../variants/$name.o correlation_fwd2.hip
   objs=""
-  for o in api warp census stencil stacked correlation correlation_mfma correlation_fwd2 correlation_f16; do
+  for o in api warp census stencil stacked correlation correlation_mfma correlation_fwd2 correlation_bwd4 correlation_f16; do
     if [ "$o" = "correlation_fwd2" ]; then objs="$objs ../variants/$name.o"; else objs="$objs $o.o"; fi
   done
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../variants/$name.so $objs

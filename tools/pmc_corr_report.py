@@ -9,8 +9,8 @@ def grab(block, name):
 
 
 blocks = raw.split("== ")[1:]
-fwd = [b for b in blocks if b.startswith("Li4ELb0")][0]
-bwd = [b for b in blocks if b.startswith("void unflow")][0]
+fwd = [b for b in blocks if b.startswith("corr_fwd2_kernel")][0]
+bwd = [b for b in blocks if b.startswith("corr_mfma_bwd4_kernel")][0]
 
 
 def line(tag, b):
@@ -27,9 +27,9 @@ print("""PMC counters of the correlation kernels (tools/profile_round.sh: rocpro
 MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs):
 %s
 %s
-(round 1, profiles/r01f_pmc_corr.txt: forward 61.9 %% busy, 33 %% LDS conflicts; backward 58.9 %% busy, 59 %% LDS conflicts)
+(round 3, profiles/r03_pmc_corr.txt: forward 63.1 %% busy, 33 %% LDS conflicts; backward 69.8 %% busy, 28 %% LDS conflicts)
 
 ---- forward
 == %s
 ---- backward (mean of the two gradient launches of one call; FETCH_SIZE / WRITE_SIZE in KB)
-== %s""" % (line("forward (corr_mfma_fwd_half_kernel<4,false>)", fwd), line("backward, one gradient (corr_mfma_bwd4_kernel<WRT1>)", bwd), fwd, bwd))
+== %s""" % (line("forward (corr_fwd2_kernel)", fwd), line("backward, one gradient (corr_mfma_bwd4_kernel<WRT1>)", bwd), fwd, bwd))

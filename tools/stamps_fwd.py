@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["UNFLOW_HIP_LIB"])
 BLOCKS, ROWS, PER = 8, 128, 4
 buf = np.zeros(BLOCKS * 2 * (ROWS + 1) * PER, np.uint64)
-assert lib.unflow_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes)) == 0
+assert lib.unflow_debug_read_fwd_stamps(buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes)) == 0
 st = buf.reshape(BLOCKS, 2, ROWS + 1, PER).astype(np.int64)
 print("variant", os.path.basename(sys.argv[1]))
 for blk in (0, 1, 4, 5):

@@ -12,7 +12,7 @@ while [ $# -gt 1 ]; do
   name=$1; extra=$2; shift 2
   $HIPCC $FLAGS $extra -c -o ../variants/$name.o $src
   objs=""
-  for o in api warp census stencil stacked correlation correlation_mfma correlation_fwd2 correlation_f16; do
+  for o in api warp census stencil stacked correlation correlation_mfma correlation_fwd2 correlation_bwd4 correlation_f16; do
     if [ "$o.hip" = "$src" ]; then objs="$objs ../variants/$name.o"; else objs="$objs $o.o"; fi
   done
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o ../variants/$name.so $objs

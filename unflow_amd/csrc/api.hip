@@ -61,8 +61,8 @@ extern "C" const char *unflow_build_flags(void) {
   static char buf[256] = {0};
   static bool done = false;
   if (!done) {      // idempotent: both parts are string literals
-    snprintf(buf, sizeof(buf), "%s%s%s", unflow::tune_flags_correlation_mfma(), unflow::tune_flags_correlation_fwd2(),
-             unflow::tune_flags_warp());
+    snprintf(buf, sizeof(buf), "%s%s%s%s", unflow::tune_flags_correlation_mfma(), unflow::tune_flags_correlation_fwd2(),
+             unflow::tune_flags_correlation_bwd4(), unflow::tune_flags_warp());
     done = true;
   }
   return buf;

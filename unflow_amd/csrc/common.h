@@ -19,6 +19,7 @@ int fail(int code, const char *fmt, ...);
 // joins them behind unflow_build_flags() so that a diagnostic build cannot pass for the real library.
 const char *tune_flags_correlation_mfma();
 const char *tune_flags_correlation_fwd2();
+const char *tune_flags_correlation_bwd4();
 const char *tune_flags_warp();
 
 // hipGetLastError() after a launch; never synchronises.

@@ -29,8 +29,12 @@ int corr_mfma_fwd_f16(const void *in0, const void *in1, void *out, int B, int C,
                       hipStream_t s);
 int corr_mfma_bwd_f16(const void *topdiff, const void *in0, const void *in1, void *g0, void *g1, int B, int C,
                       const CorrGeometry &g, hipStream_t s);
+// float32 backward: correlation_bwd4.hip (C % 128 == 0, 16-byte aligned rows), everything else corr_mfma_bwd_r1
 int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,
                   const CorrGeometry &g, hipStream_t s);
+// first-generation row sweep (correlation_mfma.hip): any channel count, 4-byte aligned rows
+int corr_mfma_bwd_r1(const float *topdiff, const float *in0, const float *in1, float *g0, float *g1, int B, int C,
+                     const CorrGeometry &g, hipStream_t s);
 // f16 matrix cores (correlation_f16.hip): half in, half out, v_mfma_f32_16x16x16_f16 (f32 accumulate)
 int corr16_fwd(const void *in0, const void *in1, void *out, int B, int C, const CorrGeometry &g, hipStream_t s);
 int corr16_bwd(const void *topdiff, const void *in0, const void *in1, void *g0, void *g1, int B, int C,
