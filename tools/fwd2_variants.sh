@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../unflow_amd/csrc"
 mkdir -p ../variants
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-pass-failed"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-pass-failed -Wno-inline-asm"
 make -s >/dev/null
 while [ $# -gt 2 ]; do
   name=$1; knobs=$2; extra=$3; shift 3

@@ -13,11 +13,14 @@
 //    (10 LDS reads per 18 MFMAs instead of 19).  Plane stride 928 floats = 32 mod 64: the two channels a half-wave
 //    reads take disjoint halves of the 64 banks, the reads are conflict free without the odd-plane shift (which would
 //    break the 8-byte alignment).
-//  * the sweep over the channels -- zeroing, prologue DMA, per chunk of 8 channels 36 MFMAs + 20 fragment reads (one
-//    K-step ahead, double-buffered registers) + 5 LDS-DMA pieces (two chunks ahead) + one barrier -- is one asm
-//    statement on fixed registers (tools/gen_corr_fwd_asm.py -> corr_fwd2_asm.inc): ~0.9 scalar and no vector ALU
-//    instruction per MFMA where the compiled loop had 2.1 + 1.2.  The accumulators are the statement's outputs, bound
-//    to their registers, and the epilogue is C++ again.
+//  * the sweep over the channels -- zeroing, prologue DMA, per K-step of 4 channels 18 MFMAs + 10 fragment reads (one
+//    K-step ahead, double-buffered registers) + 2-3 LDS-DMA pieces + one barrier -- is one asm statement on fixed
+//    registers (tools/gen_corr_fwd_asm.py -> corr_fwd2_asm.inc): ~0.7 scalar and no vector ALU instruction per MFMA
+//    where the compiled loop had 2.1 + 1.2.  The accumulators are the statement's outputs, bound to their registers,
+//    and the epilogue is C++ again.
+//  * staging: a ring of FOUR stages of four channels; the DMA of K-step j + 4 is issued behind the barrier of K-step
+//    j, three barrier intervals ahead of its use (two stages of eight channels left one to two: a wave then waited for
+//    its own DMA 8-19 % of the sweep, now 2-3 %; profiles/r04_variants.txt).
 //  * epilogue: per N-tile row the results go to an LDS slab [position row 8][window row 4][dx' + 3: 28][x 16 + 2] with
 //    one unmasked ds_write_b64 per (tile, position column) -- out-of-range dx' land in pad cells that are never read,
 //    the pitches (18, 28 * 18) make the 16 lanes of a write group hit 16 different bank pairs -- and leave as 64-byte
@@ -49,8 +52,8 @@ constexpr int RW = S * RX;                    // 16 full-resolution columns
 constexpr int NTHREADS = 512;
 constexpr unsigned OOB = 0x80000000u;         // beyond any num_records (< 2 GiB): loads return 0, stores are dropped
 constexpr int ROWF = UNFLOW_FWD2_ROWF, ROWS = UNFLOW_FWD2_ROWS, PL = UNFLOW_FWD2_PL, F0S = UNFLOW_FWD2_F0S;
-constexpr int F0OFF = UNFLOW_FWD2_F0OFF, STAGE = UNFLOW_FWD2_STAGE, NT = UNFLOW_FWD2_NT;
-constexpr int KC = 8;
+constexpr int F0OFF = UNFLOW_FWD2_F0OFF, STAGE = UNFLOW_FWD2_STAGE, NSTAGE = UNFLOW_FWD2_NSTAGE, NT = UNFLOW_FWD2_NT;
+constexpr int KS = 4;                         // channels per stage = K of the MFMA; the sweep runs in groups of NSTAGE K-steps
 static_assert(ROWF == S * (RX + 2 * R) && ROWS == RY + 8 && PL % 64 == 32 && F0S % 16 == 8, "LDS images");
 // epilogue slab of one N-tile row
 constexpr int XP = RW + 2;                    // 18: x pitch
@@ -58,8 +61,8 @@ constexpr int DXP = 28;                       // dx' + 3 in 0..26
 constexpr int QS = DXP * XP;                  // 504: window-row pitch
 constexpr int RS = 4 * QS;                    // 2016: position-row pitch
 constexpr int SLAB = RY * RS;                 // 16128 floats
-static_assert(SLAB <= 2 * STAGE, "the slab reuses the staging buffers");
-constexpr size_t LDS_BYTES = sizeof(float) * 2 * STAGE;
+static_assert(SLAB <= NSTAGE * STAGE, "the slab reuses the staging buffers");
+constexpr size_t LDS_BYTES = sizeof(float) * NSTAGE * STAGE;
 
 // A 16-byte store and the two wait states gfx950 needs before a VALU instruction may overwrite its data registers
 // (tools/check_store_hazard.py; the compiler pads nothing when the scalar offset is a register), as one statement so
@@ -113,51 +116,50 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
   f32x4 acc[NT];
   {
     const int k = lane >> 4, n = lane & 15;
-#ifdef UNFLOW_FWD2_DIRECT_STORES
-    // M index of the MFMA = 4 * px + py: the D rows 4 * (lane >> 4) + j put the position COLUMN on the lanes
-    const unsigned aaddr = lds0 + 4u * (unsigned)(F0OFF + k * F0S + (ty * TP + (n & 3)) * RW + S * (tx * TP + (n >> 2)));
-#else
     const unsigned aaddr = lds0 + 4u * (unsigned)(F0OFF + k * F0S + (ty * TP + (n >> 2)) * RW + S * (tx * TP + (n & 3)));
-#endif
     const unsigned baddr = lds0 + 4u * (unsigned)(k * PL + (ty * TP + (n >> 2)) * ROWF + S * (tx * TP + (n & 3)) + 24 * nh);
-    // LDS-DMA: wave w stages channel w of the chunk -- 16 window rows of f1 (3 1/2 pieces of 1 KiB) and the 8 x 16
-    // positions of f0 (half a piece).  X and W are multiples of 4: a 16-byte segment is inside or outside as a whole;
-    // outside (zero padding) it reads beyond num_records and returns 0.
-    unsigned voff[5];
+#ifdef UNFLOW_TUNE_FWD2_STAMPS
+    unsigned accv = 0, accb = 0;
+    st_t0 = __builtin_amdgcn_s_memtime();
+    st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // LDS-DMA into a ring of four stages of four channels.  Wave w stages channel w & 3 of a K-step: waves 0..3 the f1
+    // pieces 0, 1, 2 (16 window rows of 56 floats = 3 1/2 pieces of 1 KiB), waves 4..7 the half piece 3 and the 8 x 16
+    // positions of f0 (half a piece), lanes 0..31.  X and W are multiples of 4: a 16-byte segment is inside or outside
+    // as a whole; outside (zero padding) it reads beyond num_records and returns 0.
+    const int chn = wave & 3, cls = __builtin_amdgcn_readfirstlane(wave >> 2);
+    unsigned vp[4], vf0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int f = (j * 64 + lane) * 4;
       const int row = f / ROWF, x = f - row * ROWF;
       const int Y = S * (ys0 - R + 12 * half + row) + cy, X = S * (xs0 - R) + x;
       const bool in = f < ROWS * ROWF && Y >= 0 && Y < H && X >= 0 && X < W;
-      voff[j] = in ? (unsigned)((wave * plane + (long long)Y * W + X) * 4) : OOB;
+      vp[j] = in ? (unsigned)((chn * plane + (long long)Y * W + X) * 4) : OOB;
     }
     {
       const int f = (lane & 31) * 4;
       const int row = f / RW, x = f - row * RW;
       const int Y = S * (ys0 + row) + cy, X = S * xs0 + x;
-      voff[4] = Y < H && X < W ? (unsigned)((wave * plane + (long long)Y * W + X) * 4) : OOB;
+      vf0 = Y < H && X < W ? (unsigned)((chn * plane + (long long)Y * W + X) * 4) : OOB;
     }
-#ifdef UNFLOW_TUNE_FWD2_OOBDMA       // timing only: every DMA lane out of range (zeros, nothing fetched)
-#pragma unroll
-    for (int j = 0; j < 5; ++j) voff[j] = C > 0 ? OOB : voff[j];
-#endif
     const unsigned bytes = (unsigned)((long long)C * plane * 4);
-    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in0 + item * C * plane), (short)0, (int)bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in1 + item * C * plane), (short)0, (int)bytes, 0x00020000);
-    const unsigned m1 = lds0 + 4u * (unsigned)(wave * PL), m0f = lds0 + 4u * (unsigned)(F0OFF + wave * F0S);
-    const unsigned cstep = (unsigned)(KC * plane * 4), npairs = (unsigned)(C / (2 * KC));
+    const unsigned vA = cls ? vp[3] : vp[0], vB = cls ? vf0 : vp[1], vC = cls ? OOB : vp[2];
+    const unsigned pl0 = lds0 + 4u * (unsigned)(chn * PL);
+#define UNFLOW_UNI(x) (unsigned)__builtin_amdgcn_readfirstlane((int)(x))
+    const unsigned mA = UNFLOW_UNI(cls ? pl0 + 3072u : pl0), mB = UNFLOW_UNI(cls ? lds0 + 4u * (unsigned)(F0OFF + chn * F0S) : pl0 + 1024u),
+                   mC = UNFLOW_UNI(pl0 + 2048u);   // (waves 4..7 issue two pieces: [vC] [mC] unused)
+    const unsigned ehi = UNFLOW_UNI(cls ? 0u : 0xffffffffu);
+#undef UNFLOW_UNI
+    const __amdgpu_buffer_rsrc_t rA = r1, rC = r1;
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((cls ? in0 : in1) + item * C * plane), (short)0, (int)bytes, 0x00020000);
+    const unsigned kstep = (unsigned)(KS * plane * 4), ngroups = (unsigned)(C / (KS * NSTAGE));
     unsigned soff, cnt;
-#ifdef UNFLOW_TUNE_FWD2_STAMPS
-    unsigned accv = 0, accb = 0;
-    st_t0 = __builtin_amdgcn_s_memtime();
-    st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
     asm volatile(UNFLOW_FWD2_MAIN
                  : UNFLOW_FWD2_ACC_OUTPUTS(acc), [soff] "=&s"(soff), [cnt] "=&s"(cnt) UNFLOW_FWD2_STAMP_OPERANDS
-                 : [aaddr] "v"(aaddr), [baddr] "v"(baddr), [v0] "v"(voff[0]), [v1] "v"(voff[1]), [v2] "v"(voff[2]),
-                   [v3] "v"(voff[3]), [v4] "v"(voff[4]), [r0] "s"(r0), [r1] "s"(r1), [mask] "s"(rowmask), [m1] "s"(m1),
-                   [m0f] "s"(m0f), [cstep] "s"(cstep), [npairs] "s"(npairs)
+                 : [aaddr] "v"(aaddr), [baddr] "v"(baddr), [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [rA] "s"(rA), [rB] "s"(rB), [rC] "s"(rC),
+                   [mask] "s"(rowmask), [mA] "s"(mA), [mB] "s"(mB), [mC] "s"(mC), [ehi] "s"(ehi), [kstep] "s"(kstep), [ngroups] "s"(ngroups)
                  : UNFLOW_FWD2_FRAG_CLOBBERS, "scc", "m0", "memory" UNFLOW_FWD2_STAMP_CLOBBERS);
 #ifdef UNFLOW_TUNE_FWD2_STAMPS
     st_t1 = __builtin_amdgcn_s_memtime();
@@ -174,44 +176,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
   asm volatile("" : "+v"(tid));
   const bool pow2 = (C & (C - 1)) == 0;
   const float scale = 1.f / (float)C, fc = (float)C;
-#ifdef UNFLOW_FWD2_DIRECT_STORES
-  // Results leave straight from the accumulators: lane = (px = lane >> 4, window (qyl, qxl) = lane & 15), register j =
-  // position row; the two column classes of a position are adjacent floats of the output row -> one 8-byte store per
-  // (tile, j), four lanes (px) make 32 contiguous bytes.  Offsets below zero or beyond the 441 planes (dy' outside
-  // 0..20) fall to the buffer range check; dx' outside 0..20 and columns beyond W are sent there explicitly.
-  {
-    const int px = (tid & 63) >> 4, nn = tid & 15, qyl = nn >> 2, qxl = nn & 3;
-    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(out + item * (GW * GW) * plane, (short)0,
-                                                                         (int)((long long)GW * GW * plane * 4), 0x00020000);
-    const int X = S * (xs0 + tx * TP + px);
-    const long long lane_off = (((long long)(12 * half + qyl) * GW + (12 * nh + qxl - px)) * plane + (long long)(S * (ys0 + ty * TP) + cy) * W + X) * 4;
-    int base[3];
-#pragma unroll
-    for (int col = 0; col < 3; ++col) {
-      const int dx = 12 * nh + 4 * col + qxl - px;
-      base[col] = dx >= 0 && dx <= 2 * R && X < W ? (int)(lane_off + (long long)col * 16 * plane) : (int)0x40000000;
-    }
-    auto direct = [&](auto POW2) {
-      constexpr bool p2 = decltype(POW2)::value;
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (S * (ys0 + ty * TP + j) + cy >= H) continue;        // (wave-uniform)
-          const int sc = (int)((((long long)(4 * r - j) * GW) * plane + (long long)S * j * W) * 4);
-#pragma unroll
-          for (int col = 0; col < 3; ++col) {
-            const float v0 = acc[(r * 3 + col) * 2 + 0][j], v1 = acc[(r * 3 + col) * 2 + 1][j];
-            const f32x2 v = p2 ? f32x2{v0 * scale, v1 * scale} : f32x2{v0 / fc, v1 / fc};
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), ro, base[col] + sc, 0, 0);
-          }
-        }
-      }
-    };
-    if (pow2) direct(std::true_type{});
-    else direct(std::false_type{});
-  }
-#else
   const int py = (tid & 63) >> 4, n = tid & 15;
   // slab cell of (col 0, j 0): [row][n / 4][4 (3 nh) + n % 4 + 3][2 (4 tx)]; + col * 4 * XP, + j * (2 - XP)
   float *const wr = lds + (ty * TP + py) * RS + (n >> 2) * QS + (12 * nh + (n & 3) + 3) * XP + S * TP * tx;
@@ -262,7 +226,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
     if (pow2) epilogue(std::true_type{});
     else epilogue(std::false_type{});
   }
-#endif   // UNFLOW_FWD2_DIRECT_STORES
 #ifdef UNFLOW_TUNE_FWD2_STAMPS
   if ((int)blockIdx.x % 61 == 0 && (int)blockIdx.x / 61 < STAMP_SLOTS && (tid & 63) == 0) {
     unsigned long long *d = g_fwd2_stamps + (((int)blockIdx.x / 61) * 8 + (tid >> 6)) * STAMP_WORDS;
@@ -286,7 +249,7 @@ bool corr_fwd2_supported(const CorrGeometry &g, int C, const void *in0, const vo
   auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   // whole chunk pairs (the channel tail would need the buffer range check, which the scalar chunk offset bypasses),
   // 16-byte row segments, one pair's tensors inside a 2 GiB buffer descriptor
-  return corr_mfma_supported(g, C) && C % (2 * KC) == 0 && g.W % 4 == 0 && al16(in0) && al16(in1) && al16(out) &&
+  return corr_mfma_supported(g, C) && C % (KS * NSTAGE) == 0 && g.W % 4 == 0 && al16(in0) && al16(in1) && al16(out) &&
          (long long)GW * GW * g.H * g.W * 4 < (1LL << 31);
 }
 
@@ -324,9 +287,6 @@ const char *tune_flags_correlation_fwd2() {
 #endif
 #ifdef UNFLOW_TUNE_FWD2_NOSTORE
          " UNFLOW_TUNE_FWD2_NOSTORE"
-#endif
-#ifdef UNFLOW_TUNE_FWD2_OOBDMA
-         " UNFLOW_TUNE_FWD2_OOBDMA"
 #endif
 #ifdef UNFLOW_TUNE_FWD2_NOEPI
          " UNFLOW_TUNE_FWD2_NOEPI"
