@@ -28,8 +28,10 @@ python tools/pmc_corr_report.py $O/${tag}_pmc_corr_raw.txt > $O/${tag}_pmc_corr.
 timeout -k 10 200 python bench.py --config cfg2 --steps 20 --warmup 5 > $O/${tag}_bench_line_cfg2.json 2> $O/cfg2.err; echo "cfg2 done"
 timeout -k 10 200 python bench.py --config cfg5 --steps 20 --warmup 5 > $O/${tag}_bench_line_cfg5.json 2> $O/cfg5.err; echo "cfg5 done"
 timeout -k 10 200 python tools/corr16_time.py > $O/${tag}_corr16_time.txt 2>&1; echo "corr16 timing done"
-bash tools/pmc_corr16.sh fwd > $O/${tag}_pmc_corr16_fwd.txt 2>&1
-bash tools/pmc_corr16.sh bwd > $O/${tag}_pmc_corr16_bwd.txt 2>&1; echo "corr16 pmc done"
-bash tools/pmc_loss_step.sh > $O/pmc_loss_step.log 2>&1
-cp gpurun_out/r03_pmc_loss.txt $O/${tag}_pmc_loss.txt 2>/dev/null; cp gpurun_out/r03_pmc_loss.json $O/${tag}_pmc_loss.json 2>/dev/null; echo "loss pmc done"
+if [ -z "$SKIP_UNCHANGED" ]; then     # (SKIP_UNCHANGED=1: a round that did not touch the f16 correlation and the loss kernels)
+  bash tools/pmc_corr16.sh fwd > $O/${tag}_pmc_corr16_fwd.txt 2>&1
+  bash tools/pmc_corr16.sh bwd > $O/${tag}_pmc_corr16_bwd.txt 2>&1; echo "corr16 pmc done"
+  bash tools/pmc_loss_step.sh > $O/pmc_loss_step.log 2>&1
+  cp gpurun_out/r03_pmc_loss.txt $O/${tag}_pmc_loss.txt 2>/dev/null; cp gpurun_out/r03_pmc_loss.json $O/${tag}_pmc_loss.json 2>/dev/null; echo "loss pmc done"
+fi
 cat $O/${tag}_traffic.json | head -12
