@@ -191,6 +191,11 @@ def test_seeded_extensions(seeded, dev):
     ((66, 256, 5, 8), dict()),
     # C % 128 == 0 but not a power of two: the tile stores divide by C instead of multiplying by 1/C
     ((2, 384, 13, 20), dict()),
+    # the forward's ring of four 4-channel stages (corr_fwd2_kernel, C % 16 == 0 and W % 4 == 0): one group of four K-steps
+    # (prologue and tail only), three groups, a channel count that is not a power of two, regions that leave the image
+    ((1, 16, 8, 8), dict()),
+    ((2, 48, 10, 12), dict()),
+    ((1, 80, 21, 36), dict()),
     ((2, 6, 10, 12), dict(kernel_size=3, max_displacement=4, pad=3, stride_1=2, stride_2=2)),
     ((1, 5, 9, 11), dict(kernel_size=1, max_displacement=5, pad=2, stride_1=1, stride_2=2)),
     ((1, 4, 12, 9), dict(kernel_size=5, max_displacement=3, pad=6, stride_1=3, stride_2=1)),
