@@ -189,16 +189,15 @@ class Workload:
         self.flow_bw = (-self.flow_fw.detach() + 0.5 * smooth_flow(torch, gen, B) * 0.1).requires_grad_(True)
         self.border = losses.create_border_mask(self.im1, 0.1)
         self.grad_buffer = udist.FlatGradBuffer(GRAD_BUFFER_FLOATS, dev) if features else None
-        self.corr_events = []   # (start, end, kind) HIP events on the launch stream
+        self.corr_events = []   # (start, end, kind, calls between them): HIP events on the launch stream
 
-    def _timed(self, kind, fn, *a, **k):
-        torch = self.torch
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        r = fn(*a, **k)
-        e.record()
-        self.corr_events.append((s, e, kind))
-        return r
+    def _mark(self):
+        """One HIP event on the launch stream (the stream the ABI is given).  An event record costs the stream a
+        marker packet and ~5-10 us between two kernels (rocprofv3 trace of the step), so the step brackets each PAIR of
+        correlation calls with ONE event on either side -- three per step -- instead of two per call."""
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
 
     def loss_leg(self):
         """The loss half of the step: level-0 compute_losses (fused census/warp and occlusion
@@ -228,10 +227,14 @@ class Workload:
                 g_fw = ops.correlation_grad(ops.correlation_flip(self.top_bw, self.top_fw), self.fa, self.fb)
                 g_bw = None
             else:
-                c_fw = self._timed("corr_fwd", ops.correlation, self.fa, self.fb)
-                c_bw = self._timed("corr_fwd", ops.correlation, self.fb, self.fa)
-                g_fw = self._timed("corr_bwd", ops.correlation_grad, self.top_fw, self.fa, self.fb)
-                g_bw = self._timed("corr_bwd", ops.correlation_grad, self.top_bw, self.fb, self.fa)
+                e0 = self._mark()
+                c_fw = ops.correlation(self.fa, self.fb)
+                c_bw = ops.correlation(self.fb, self.fa)
+                e1 = self._mark()
+                g_fw = ops.correlation_grad(self.top_fw, self.fa, self.fb)
+                g_bw = ops.correlation_grad(self.top_bw, self.fb, self.fa)
+                e2 = self._mark()
+                self.corr_events += [(e0, e1, "corr_fwd", 2), (e1, e2, "corr_bwd", 2)]    # (start, end, kind, calls)
             order += ["corr_fwd", "corr_fwd", "corr_bwd", "corr_bwd"]
         # N > 1: the gradient buffer stands for the FlowNetC weights' gradient, which a trainer has at the
         # earliest when the correlation backward is through (core/train.py:446-480 averages after the whole
@@ -712,8 +715,8 @@ def main():
 
     # dominant kernel: correlation backward (3.47 GFLOP/pair, f32 MFMA); averaged over the timed region
     per_kind = {}
-    for s, e, kind in wl.corr_events:
-        per_kind.setdefault(kind, []).append(s.elapsed_time(e))
+    for s, e, kind, calls in wl.corr_events:
+        per_kind.setdefault(kind, []).append(s.elapsed_time(e) / calls)      # per call
     bwd_ms = float(np.mean(per_kind["corr_bwd"]))
     fwd_ms = float(np.mean(per_kind["corr_fwd"]))
 
@@ -777,7 +780,8 @@ def main():
                          "kernel": "correlation backward: corr_mfma_bwd4_kernel, both gradient launches of one call",
                          "achieved": achieved_tf, "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP32_MATRIX_PEAK_TF,
-                         "frac_basis": "HIP events around the call on the launch stream, mean over the timed region "
+                         "frac_basis": "HIP events on the launch stream around the step's two correlation_grad calls (one event before, one "
+                                       "behind the pair: per call = half), mean over the timed region "
                                        "(rocprofv3 kernel averages of the same command: profiles/r04_bench_kernel_stats.csv)",
                          "traffic": traffic, "traffic_source": traffic_src,
                          "stream_copy_gbs": copy_gbs,
