@@ -52,9 +52,14 @@ constexpr int RW = S * RX;                    // 16 full-resolution columns
 constexpr int NTHREADS = 512;
 constexpr unsigned OOB = 0x80000000u;         // beyond any num_records (< 2 GiB): loads return 0, stores are dropped
 constexpr int ROWF = UNFLOW_FWD2_ROWF, ROWS = UNFLOW_FWD2_ROWS, PL = UNFLOW_FWD2_PL, F0S = UNFLOW_FWD2_F0S;
-constexpr int F0OFF = UNFLOW_FWD2_F0OFF, STAGE = UNFLOW_FWD2_STAGE, NSTAGE = UNFLOW_FWD2_NSTAGE, NT = UNFLOW_FWD2_NT;
+constexpr int F0OFF = UNFLOW_FWD2_F0OFF, STAGE = UNFLOW_FWD2_STAGE, NSTAGE = UNFLOW_FWD2_NSTAGE, NT = UNFLOW_FWD2_NT, NROW = UNFLOW_FWD2_NROW;
+#ifdef UNFLOW_FWD2_FULLWIN      // experiment (tools/gen_corr_fwd_asm.py FWD2_FULL=1): the whole window per workgroup, one workgroup per CU
+constexpr int NHALF = 1, MIN_WAVES = 2;
+#else
+constexpr int NHALF = 2, MIN_WAVES = 4;
+#endif
 constexpr int KS = 4;                         // channels per stage = K of the MFMA; the sweep runs in groups of NSTAGE K-steps
-static_assert(ROWF == S * (RX + 2 * R) && ROWS == RY + 8 && PL % 64 == 32 && F0S % 16 == 8, "LDS images");
+static_assert(ROWF == S * (RX + 2 * R) && ROWS == RY + 4 * NROW - 4 && PL % 64 == 32 && F0S % 16 == 8, "LDS images");
 // epilogue slab of one N-tile row
 constexpr int XP = RW + 2;                    // 18: x pitch
 constexpr int DXP = 28;                       // dx' + 3 in 0..26
@@ -81,7 +86,7 @@ __device__ unsigned long long g_fwd2_stamps[STAMP_SLOTS * 8 * STAMP_WORDS];
 
 __device__ inline int xcd_remap(int b, int nblk) { return (nblk & 7) == 0 ? (b & 7) * (nblk >> 3) + (b >> 3) : b; }
 
-__global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__restrict__ in0, const float *__restrict__ in1,
+__global__ __launch_bounds__(NTHREADS, MIN_WAVES) void corr_fwd2_kernel(const float *__restrict__ in0, const float *__restrict__ in1,
                                                                 float *__restrict__ out, int C, int H, int W, int nbx,
                                                                 int nby) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -89,8 +94,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nh = wave & 1, tx = (wave >> 1) & 1, ty = wave >> 2;
   int vb = xcd_remap(blockIdx.x, gridDim.x);
-  const int half = vb & 1;                     // which three N-tile rows of the region's window
-  vb >>= 1;
+  const int half = NHALF == 2 ? vb & 1 : 0;    // which three N-tile rows of the region's window
+  if (NHALF == 2) vb >>= 1;
   const int bx = vb % nbx, by = (vb / nbx) % nby, bz = vb / (nbx * nby);
   const int cy = bz & 1;
   const long long item = bz >> 1;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
   // N-tile rows of this wave that meet the image (the others multiply zero padding: skipped)
   unsigned rowmask = 0;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
+  for (int q = 0; q < NROW; ++q) {
     const int r0 = ys0 + ty * TP - R + 4 * (3 * half + q);
     if (r0 + 3 >= 0 && r0 < hs) rowmask |= 1u << q;
   }
@@ -128,9 +133,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
     // positions of f0 (half a piece), lanes 0..31.  X and W are multiples of 4: a 16-byte segment is inside or outside
     // as a whole; outside (zero padding) it reads beyond num_records and returns 0.
     const int chn = wave & 3, cls = __builtin_amdgcn_readfirstlane(wave >> 2);
-    unsigned vp[4], vf0;
+    constexpr int NPIECE = (ROWS * ROWF + 255) / 256;      // 1-KiB pieces of an f1 plane (the last one partial)
+    unsigned vp[NPIECE], vf0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NPIECE; ++j) {
       const int f = (j * 64 + lane) * 4;
       const int row = f / ROWF, x = f - row * ROWF;
       const int Y = S * (ys0 - R + 12 * half + row) + cy, X = S * (xs0 - R) + x;
@@ -145,20 +151,32 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
     }
     const unsigned bytes = (unsigned)((long long)C * plane * 4);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(in1 + item * C * plane), (short)0, (int)bytes, 0x00020000);
-    const unsigned vA = cls ? vp[3] : vp[0], vB = cls ? vf0 : vp[1], vC = cls ? OOB : vp[2];
-    const unsigned pl0 = lds0 + 4u * (unsigned)(chn * PL);
+    const unsigned pl0 = lds0 + 4u * (unsigned)(chn * PL), f0dst = lds0 + 4u * (unsigned)(F0OFF + chn * F0S);
 #define UNFLOW_UNI(x) (unsigned)__builtin_amdgcn_readfirstlane((int)(x))
-    const unsigned mA = UNFLOW_UNI(cls ? pl0 + 3072u : pl0), mB = UNFLOW_UNI(cls ? lds0 + 4u * (unsigned)(F0OFF + chn * F0S) : pl0 + 1024u),
-                   mC = UNFLOW_UNI(pl0 + 2048u);   // (waves 4..7 issue two pieces: [vC] [mC] unused)
     const unsigned ehi = UNFLOW_UNI(cls ? 0u : 0xffffffffu);
-#undef UNFLOW_UNI
+#ifdef UNFLOW_FWD2_FULLWIN
+    // waves 0..3: pieces 0..3; waves 4..7: pieces 4, 5, the 8 lanes of piece 6 and the f0 plane
+    const unsigned vA = cls ? vp[4] : vp[0], vB = cls ? vp[5] : vp[1], vC = cls ? vp[6] : vp[2], vD = cls ? vf0 : vp[3];
+    const unsigned mA = UNFLOW_UNI(cls ? pl0 + 4096u : pl0), mB = UNFLOW_UNI(cls ? pl0 + 5120u : pl0 + 1024u),
+                   mC = UNFLOW_UNI(cls ? pl0 + 6144u : pl0 + 2048u), mD = UNFLOW_UNI(cls ? f0dst : pl0 + 3072u);
+    const __amdgpu_buffer_rsrc_t rA = r1, rB = r1, rC = r1;
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((cls ? in0 : in1) + item * C * plane), (short)0, (int)bytes, 0x00020000);
+#else
+    const unsigned vA = cls ? vp[3] : vp[0], vB = cls ? vf0 : vp[1], vC = cls ? OOB : vp[2];
+    const unsigned mA = UNFLOW_UNI(cls ? pl0 + 3072u : pl0), mB = UNFLOW_UNI(cls ? f0dst : pl0 + 1024u),
+                   mC = UNFLOW_UNI(pl0 + 2048u);   // (waves 4..7 issue two pieces: [vC] [mC] unused)
     const __amdgpu_buffer_rsrc_t rA = r1, rC = r1;
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>((cls ? in0 : in1) + item * C * plane), (short)0, (int)bytes, 0x00020000);
+#endif
+#undef UNFLOW_UNI
     const unsigned kstep = (unsigned)(KS * plane * 4), ngroups = (unsigned)(C / (KS * NSTAGE));
     unsigned soff, cnt;
     asm volatile(UNFLOW_FWD2_MAIN
                  : UNFLOW_FWD2_ACC_OUTPUTS(acc), [soff] "=&s"(soff), [cnt] "=&s"(cnt) UNFLOW_FWD2_STAMP_OPERANDS
                  : [aaddr] "v"(aaddr), [baddr] "v"(baddr), [vA] "v"(vA), [vB] "v"(vB), [vC] "v"(vC), [rA] "s"(rA), [rB] "s"(rB), [rC] "s"(rC),
+#ifdef UNFLOW_FWD2_FULLWIN
+                   [vD] "v"(vD), [rD] "s"(rD), [mD] "s"(mD), [aaddr2] "v"(aaddr + 2u * STAGE * 4u), [baddr2] "v"(baddr + 2u * STAGE * 4u),
+#endif
                    [mask] "s"(rowmask), [mA] "s"(mA), [mB] "s"(mB), [mC] "s"(mC), [ehi] "s"(ehi), [kstep] "s"(kstep), [ngroups] "s"(ngroups)
                  : UNFLOW_FWD2_FRAG_CLOBBERS, "scc", "m0", "memory" UNFLOW_FWD2_STAMP_CLOBBERS);
 #ifdef UNFLOW_TUNE_FWD2_STAMPS
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
   auto epilogue = [&](auto POW2) {
     constexpr bool p2 = decltype(POW2)::value;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < NROW; ++r) {
 #pragma unroll
       for (int col = 0; col < 3; ++col) {
 #pragma unroll
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void corr_fwd2_kernel(const float *__r
         const f32x4 v = {lo.x, lo.y, hi.x, hi.y};
         store_b128(v, ro, i == 5 ? vo5 : vo, (unsigned)(i * step4));
       }
-      if (r < 2) __syncthreads();
+      if (r < NROW - 1) __syncthreads();
     }
   };
 #ifdef UNFLOW_TUNE_FWD2_NOEPI
@@ -268,7 +286,7 @@ int corr_fwd2(const float *in0, const float *in1, float *out, int B, int C, cons
       return fail(UNFLOW_ERR_LAUNCH, "correlation_fwd: cannot reserve %zu B of LDS (%s)", LDS_BYTES, hipGetErrorString(st));
     if (tracked) granted[dev].store(true, std::memory_order_release);
   }
-  hipLaunchKernelGGL(corr_fwd2_kernel, dim3(nbx * nby * B * S * 2), dim3(NTHREADS), LDS_BYTES, s, in0, in1, out, C, H, W, nbx, nby);
+  hipLaunchKernelGGL(corr_fwd2_kernel, dim3(nbx * nby * B * S * NHALF), dim3(NTHREADS), LDS_BYTES, s, in0, in1, out, C, H, W, nbx, nby);
   return launch_status("correlation_fwd (mfma, instruction blocks)");
 }
 
@@ -282,6 +300,9 @@ extern "C" int unflow_debug_read_fwd2_stamps(void *dst, size_t bytes) {
 namespace unflow {
 const char *tune_flags_correlation_fwd2() {
   return ""
+#ifdef UNFLOW_FWD2_FULLWIN
+         " UNFLOW_FWD2_FULLWIN"
+#endif
 #ifdef UNFLOW_FWD2_GENERATOR_KNOBS
          " " UNFLOW_FWD2_GENERATOR_KNOBS
 #endif
