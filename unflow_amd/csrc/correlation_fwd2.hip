@@ -15,8 +15,9 @@
 //    break the 8-byte alignment).
 //  * the sweep over the channels -- zeroing, prologue DMA, per K-step of 4 channels 18 MFMAs + 10 fragment reads (one
 //    K-step ahead, double-buffered registers) + 2-3 LDS-DMA pieces + one barrier -- is one asm statement on fixed
-//    registers (tools/gen_corr_fwd_asm.py -> corr_fwd2_asm.inc): ~0.7 scalar and no vector ALU instruction per MFMA
-//    where the compiled loop had 2.1 + 1.2.  The accumulators are the statement's outputs, bound to their registers,
+//    registers (tools/gen_corr_fwd_asm.py -> corr_fwd2_asm.inc): ~0.8 scalar and no vector ALU instruction per MFMA
+//    where the compiled loop had 2.1 + 1.2.  (The statement narrows EXEC around half pieces and restores it to all ones: every
+//    launch has whole 512-thread workgroups and the only early exit is workgroup-uniform.)  The accumulators are the statement's outputs, bound to their registers,
 //    and the epilogue is C++ again.
 //  * staging: a ring of FOUR stages of four channels; the DMA of K-step j + 4 is issued behind the barrier of K-step
 //    j, three barrier intervals ahead of its use (two stages of eight channels left one to two: a wave then waited for
