@@ -525,7 +525,7 @@ def test_census_vs_oracle(oracle_mod, dev, B, H, W, r):
     assert np.abs(got_dist - want_dist).mean() <= 1e-6 * P2
     x = T(im2, dev).requires_grad_(True)
     loss = losses.ternary_loss(T(im1, dev), x, T(mask, dev), max_distance=r)
-    np.testing.assert_allclose(float(loss), want_loss, rtol=1e-5)
+    np.testing.assert_allclose(float(loss.detach()), want_loss, rtol=1e-5)
     (loss * 2.5).backward()
     want_grad = oracle_mod.ternary_loss_grad(im1, im2, mask, r, gout=2.5)
     close(x.grad, want_grad, 1e-5, 1e-5 * np.abs(want_grad).max())      # measured 4e-7 of the scale
@@ -643,7 +643,7 @@ def test_compute_losses_vs_oracle(oracle_mod, dev, mask_occlusion, use_border):
     close(aux["im2_warped"], waux["im2_warped"])
     assert set(got) == {"sym", "occ", "photo", "grad", "smooth_1st", "smooth_2nd", "fb", "ternary"}  # losses.py:60-85
     for k in ("ternary", "occ", "fb", "photo", "sym", "grad", "smooth_1st", "smooth_2nd"):
-        np.testing.assert_allclose(float(got[k]), want[k], rtol=1e-5, err_msg=k)
+        np.testing.assert_allclose(float(got[k].detach()), want[k], rtol=1e-5, err_msg=k)
     # backward to the flows through census -> image_warp
     got["ternary"].backward()
     gim2 = oracle_mod.ternary_loss_grad(im1, waux["im2_warped"], waux["mask_fw"], 3)
