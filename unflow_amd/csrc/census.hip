@@ -804,6 +804,30 @@ inline unsigned ew_grid(long long n) {
 // is slower than the unpaired kernel, 0.47 vs 0.42 ms; 0.38 ms at 8 rows; 0.31 ms with
 // dldd read in place.)
 constexpr int kPairRowsFwd = 16;   // 12 measures the same, 8 and 24+ are slower (halo rows / occupancy)
+// Rows per wave strip for an image of H rows: 16 at the full-resolution sizes; the coarse levels of the loss pyramid
+// (H = 96, 48, 24 ...) would leave a third to two thirds of a 64-row tile outside the image, so they take the strip
+// (16, 12 or 8 rows) that minimises tiles x (strip + warm-up rows).  The result does not depend on the choice (the
+// same pair sums in the same order per pixel).
+inline int pair_rows(int H, int r) {
+  int best = kPairRowsFwd;
+  long long best_cost = -1;
+  for (int rows : {16, 12, 8}) {
+    const long long tiles = (H + kPairWaves * rows - 1) / (kPairWaves * rows);
+    const long long cost = tiles * (rows + r);
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = rows;
+    }
+  }
+  return best;
+}
+// ROWS as a compile-time constant of the statement that follows (M is a macro taking ROWS)
+#define UNFLOW_PAIR_ROWS_DISPATCH(rows, M) \
+  do {                                     \
+    if ((rows) == 16) M(16);               \
+    else if ((rows) == 12) M(12);          \
+    else M(8);                             \
+  } while (0)
 inline dim3 pair_grid(int r, int rows_per_wave, int B, int H, int W) {
   const int cols = 64 - 2 * r, rows = kPairWaves * rows_per_wave;
   return dim3((W + cols - 1) / cols, (H + rows - 1) / rows, B);
@@ -979,12 +1003,17 @@ extern "C" int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped
   const int r = max_distance;
   const float inv_norm = (float)(1.0 / norm);
   if (r >= 2 && r <= 3) {
-    const dim3 pgrid = pair_grid(r, kPairRowsFwd, B, H, W);
-#define LAUNCH_PAIR_FWD(R)                                                                                     \
-  hipLaunchKernelGGL((ternary_fwd_pair_kernel<R, kPairRowsFwd>), pgrid, dim3(64 * kPairWaves),                  \
-                     (pair_smem<R, kPairRowsFwd>(2)), s, im1, im2_warped, mask, workspace, dldd, dist, H, W, inv_norm)
-    if (r == 2) LAUNCH_PAIR_FWD(2);
-    else LAUNCH_PAIR_FWD(3);
+    const int prows = pair_rows(H, r);
+    const dim3 pgrid = pair_grid(r, prows, B, H, W);
+#define LAUNCH_PAIR_FWD(R, ROWS)                                                                               \
+  hipLaunchKernelGGL((ternary_fwd_pair_kernel<R, ROWS>), pgrid, dim3(64 * kPairWaves),                          \
+                     (pair_smem<R, ROWS>(2)), s, im1, im2_warped, mask, workspace, dldd, dist, H, W, inv_norm)
+#define LAUNCH_PAIR_FWD2(ROWS) LAUNCH_PAIR_FWD(2, ROWS)
+#define LAUNCH_PAIR_FWD3(ROWS) LAUNCH_PAIR_FWD(3, ROWS)
+    if (r == 2) UNFLOW_PAIR_ROWS_DISPATCH(prows, LAUNCH_PAIR_FWD2);
+    else UNFLOW_PAIR_ROWS_DISPATCH(prows, LAUNCH_PAIR_FWD3);
+#undef LAUNCH_PAIR_FWD3
+#undef LAUNCH_PAIR_FWD2
 #undef LAUNCH_PAIR_FWD
     if (int rc = launch_status("ternary_loss_fwd")) return rc;
     return reduce_partials(workspace, (int)(pgrid.x * pgrid.y * pgrid.z), 1.0 / norm, loss, s);
@@ -1014,12 +1043,17 @@ extern "C" int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped
   hipStream_t s = as_stream(stream);
   const int r = max_distance;
   if (r >= 2 && r <= 3 && (long long)B * H * W * 4 < (1LL << 31)) {   // 32-bit byte offsets into dldd
-#define LAUNCH_PAIR_BWD(R)                                                                                     \
-  hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, kPairRowsFwd>), pair_grid(r, kPairRowsFwd, B, H, W),           \
-                     dim3(64 * kPairWaves), (pair_smem<R, kPairRowsFwd>(2)), s, im1, im2_warped, dldd, gout,    \
+    const int prows = pair_rows(H, r);
+#define LAUNCH_PAIR_BWD(R, ROWS)                                                                               \
+  hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, ROWS>), pair_grid(r, ROWS, B, H, W),                           \
+                     dim3(64 * kPairWaves), (pair_smem<R, ROWS>(2)), s, im1, im2_warped, dldd, gout,            \
                      d_im2_warped, H, W)
-    if (r == 2) LAUNCH_PAIR_BWD(2);
-    else LAUNCH_PAIR_BWD(3);
+#define LAUNCH_PAIR_BWD2(ROWS) LAUNCH_PAIR_BWD(2, ROWS)
+#define LAUNCH_PAIR_BWD3(ROWS) LAUNCH_PAIR_BWD(3, ROWS)
+    if (r == 2) UNFLOW_PAIR_ROWS_DISPATCH(prows, LAUNCH_PAIR_BWD2);
+    else UNFLOW_PAIR_ROWS_DISPATCH(prows, LAUNCH_PAIR_BWD3);
+#undef LAUNCH_PAIR_BWD3
+#undef LAUNCH_PAIR_BWD2
 #undef LAUNCH_PAIR_BWD
     return launch_status("ternary_loss_bwd");
   }
@@ -1194,14 +1228,19 @@ extern "C" int unflow_ternary_loss_warp_fwd(const float *im1, const float *im2, 
   }
   const double norm = norm_count > 0 ? (double)norm_count : (double)npix;
   const int r = max_distance;
-  const dim3 pgrid = pair_grid(r, kPairRowsFwd, B, H, W);
-#define LAUNCH_PAIR_WARP(R)                                                                                    \
-  hipLaunchKernelGGL((ternary_fwd_pair_kernel<R, kPairRowsFwd, true>), pgrid, dim3(64 * kPairWaves),            \
-                     (pair_smem<R, kPairRowsFwd>(2)), s, im1, im2, mask, workspace, dldd,                       \
+  const int prows = pair_rows(H, r);
+  const dim3 pgrid = pair_grid(r, prows, B, H, W);
+#define LAUNCH_PAIR_WARP(R, ROWS)                                                                              \
+  hipLaunchKernelGGL((ternary_fwd_pair_kernel<R, ROWS, true>), pgrid, dim3(64 * kPairWaves),                    \
+                     (pair_smem<R, ROWS>(2)), s, im1, im2, mask, workspace, dldd,                               \
                      static_cast<float *>(nullptr), H, W, (float)(1.0 / norm),                                  \
                      reinterpret_cast<const float2 *>(flow), gray1, gray2_warped)
-  if (r == 2) LAUNCH_PAIR_WARP(2);
-  else LAUNCH_PAIR_WARP(3);
+#define LAUNCH_PAIR_WARP2(ROWS) LAUNCH_PAIR_WARP(2, ROWS)
+#define LAUNCH_PAIR_WARP3(ROWS) LAUNCH_PAIR_WARP(3, ROWS)
+  if (r == 2) UNFLOW_PAIR_ROWS_DISPATCH(prows, LAUNCH_PAIR_WARP2);
+  else UNFLOW_PAIR_ROWS_DISPATCH(prows, LAUNCH_PAIR_WARP3);
+#undef LAUNCH_PAIR_WARP3
+#undef LAUNCH_PAIR_WARP2
 #undef LAUNCH_PAIR_WARP
   if (int rc = launch_status("ternary_loss_warp_fwd")) return rc;
   return reduce_partials(workspace, (int)(pgrid.x * pgrid.y * pgrid.z), 1.0 / norm, loss, s);
@@ -1218,13 +1257,18 @@ extern "C" int unflow_ternary_loss_warp_bwd(const float *gray1, const float *gra
   if ((long long)B * H * W == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
   const int r = max_distance;
-#define LAUNCH_PAIR_FUSED(R)                                                                                   \
-  hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, kPairRowsFwd, true>), pair_grid(r, kPairRowsFwd, B, H, W),     \
-                     dim3(64 * kPairWaves), (pair_smem<R, kPairRowsFwd>(2)), s, gray1, gray2_warped, dldd, gout, \
+  const int prows = pair_rows(H, r);
+#define LAUNCH_PAIR_FUSED(R, ROWS)                                                                             \
+  hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, ROWS, true>), pair_grid(r, ROWS, B, H, W),                     \
+                     dim3(64 * kPairWaves), (pair_smem<R, ROWS>(2)), s, gray1, gray2_warped, dldd, gout,        \
                      static_cast<float *>(nullptr), H, W, im2, reinterpret_cast<const float2 *>(flow),          \
                      reinterpret_cast<float2 *>(d_flow))
-  if (r == 2) LAUNCH_PAIR_FUSED(2);
-  else LAUNCH_PAIR_FUSED(3);
+#define LAUNCH_PAIR_FUSED2(ROWS) LAUNCH_PAIR_FUSED(2, ROWS)
+#define LAUNCH_PAIR_FUSED3(ROWS) LAUNCH_PAIR_FUSED(3, ROWS)
+  if (r == 2) UNFLOW_PAIR_ROWS_DISPATCH(prows, LAUNCH_PAIR_FUSED2);
+  else UNFLOW_PAIR_ROWS_DISPATCH(prows, LAUNCH_PAIR_FUSED3);
+#undef LAUNCH_PAIR_FUSED3
+#undef LAUNCH_PAIR_FUSED2
 #undef LAUNCH_PAIR_FUSED
   return launch_status("ternary_loss_warp_bwd");
 }
