@@ -531,6 +531,35 @@ def test_census_vs_oracle(oracle_mod, dev, B, H, W, r):
     close(x.grad, want_grad, 1e-5, 1e-5 * np.abs(want_grad).max())      # measured 4e-7 of the scale
 
 
+@pytest.mark.parametrize("B,H,W", [(16, 256, 640), (16, 384, 640), (24, 384, 640)])   # strips of 8, 12 and 16 rows on 256 CUs
+def test_census_strip_choice_does_not_change_results(dev, B, H, W):
+    """The pair kernels pick their rows-per-wave strip (4, 8, 12 or 16) from the launch size (census.hip pair_rows): a
+    launch that does not fill the chip takes short strips.  The per-pixel arithmetic does not depend on the strip: the
+    whole batch (long strips) must give, pixel for pixel, the gradients of its items run one at a time (one item is a
+    small launch: strips of 4), and the same loss up to the rounding of the block-partial sums."""
+    from unflow_amd import losses
+    g = torch.Generator(device=dev)
+    g.manual_seed(B + H)
+    im1 = torch.rand((B, H, W, 3), device=dev, generator=g)
+    im2 = torch.rand((B, H, W, 3), device=dev, generator=g)
+    mask = (torch.rand((B, H, W, 1), device=dev, generator=g) > 0.2).float()
+    for r in (2, 3):
+        x = im2.clone().requires_grad_(True)
+        whole = losses.ternary_loss(im1, x, mask, max_distance=r)
+        whole.backward()
+        total = 0.0
+        for b in range(0, B, max(B // 4, 1)):           # four items are enough
+            xb = im2[b:b + 1].clone().requires_grad_(True)
+            lb = losses.ternary_loss(im1[b:b + 1], xb, mask[b:b + 1], max_distance=r, norm_count=B * H * W)
+            lb.backward()
+            assert torch.equal(xb.grad, x.grad[b:b + 1]), (r, b)
+        # the loss itself: every item one at a time
+        with torch.no_grad():
+            for b in range(B):
+                total += float(losses.ternary_loss(im1[b:b + 1], im2[b:b + 1], mask[b:b + 1], max_distance=r, norm_count=B * H * W))
+        np.testing.assert_allclose(total, float(whole.detach()), rtol=1e-6)
+
+
 def test_census_backward_ignores_memory_past_its_buffers(oracle_mod, dev):
     """The pair-symmetric backward reads dldd with linear addressing and relies on the buffer
     descriptor's range check past the end: poison the allocator's free memory first."""

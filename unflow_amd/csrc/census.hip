@@ -16,6 +16,8 @@
 #include "common.h"
 #include "warp_taps.h"
 
+#include <atomic>
+#include <cstdlib>
 #include <type_traits>
 
 namespace unflow {
@@ -804,11 +806,30 @@ inline unsigned ew_grid(long long n) {
 // is slower than the unpaired kernel, 0.47 vs 0.42 ms; 0.38 ms at 8 rows; 0.31 ms with
 // dldd read in place.)
 constexpr int kPairRowsFwd = 16;   // 12 measures the same, 8 and 24+ are slower (halo rows / occupancy)
-// Rows per wave strip for an image of H rows: 16 at the full-resolution sizes; the coarse levels of the loss pyramid
-// (H = 96, 48, 24 ...) would leave a third to two thirds of a 64-row tile outside the image, so they take the strip
-// (16, 12 or 8 rows) that minimises tiles x (strip + warm-up rows).  The result does not depend on the choice (the
-// same pair sums in the same order per pixel).
-inline int pair_rows(int H, int r) {
+// Rows per wave strip.  A launch that fills the chip (full resolution) takes the strip that minimises the total work,
+// tiles x (strip + warm-up rows): 16.  The coarse levels of the loss pyramid do not fill it -- 96 x 320 x 32 pixels are
+// 384 workgroups of 64 rows -- and there the time is a workgroup's own latency, which falls with the strip: the
+// smallest strip whose launch still fits the chip at once (8 workgroups of four waves per CU) wins (KITTI-config
+// pyramid as one graph: 1.156 ms with 16 everywhere, 1.075 / 1.013 / 0.952 / 0.958 ms with 12 / 8 / 4 / 2 at the coarse
+// levels; profiles/r04_variants.txt).  The result does not depend on the choice: the same pair sums in the same
+// order per pixel.
+inline int census_cus() {
+  static std::atomic<int> cached{0};
+  int n = cached.load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cached.store(n, std::memory_order_relaxed);
+  return n;
+}
+inline int pair_rows(int B, int H, int W, int r) {
+#ifdef UNFLOW_TUNE_PAIR_ROWS      // experiment: UNFLOW_PAIR_ROWS=<16|12|8|4|2> forces the strip height for images below 200 rows
+  if (const char *e = getenv("UNFLOW_PAIR_ROWS"))
+    if (H < 200) return atoi(e);
+#endif
+  const long long xt = (W + (64 - 2 * r) - 1) / (64 - 2 * r), cap = 8LL * census_cus();
+  for (int rows : {4, 8, 12, 16})
+    if (xt * ((H + kPairWaves * rows - 1) / (kPairWaves * rows)) * B <= cap) return rows;
   int best = kPairRowsFwd;
   long long best_cost = -1;
   for (int rows : {16, 12, 8}) {
@@ -826,7 +847,8 @@ inline int pair_rows(int H, int r) {
   do {                                     \
     if ((rows) == 16) M(16);               \
     else if ((rows) == 12) M(12);          \
-    else M(8);                             \
+    else if ((rows) == 8) M(8);            \
+    else M(4);                             \
   } while (0)
 inline dim3 pair_grid(int r, int rows_per_wave, int B, int H, int W) {
   const int cols = 64 - 2 * r, rows = kPairWaves * rows_per_wave;
@@ -1003,7 +1025,7 @@ extern "C" int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped
   const int r = max_distance;
   const float inv_norm = (float)(1.0 / norm);
   if (r >= 2 && r <= 3) {
-    const int prows = pair_rows(H, r);
+    const int prows = pair_rows(B, H, W, r);
     const dim3 pgrid = pair_grid(r, prows, B, H, W);
 #define LAUNCH_PAIR_FWD(R, ROWS)                                                                               \
   hipLaunchKernelGGL((ternary_fwd_pair_kernel<R, ROWS>), pgrid, dim3(64 * kPairWaves),                          \
@@ -1043,7 +1065,7 @@ extern "C" int unflow_ternary_loss_bwd(const float *im1, const float *im2_warped
   hipStream_t s = as_stream(stream);
   const int r = max_distance;
   if (r >= 2 && r <= 3 && (long long)B * H * W * 4 < (1LL << 31)) {   // 32-bit byte offsets into dldd
-    const int prows = pair_rows(H, r);
+    const int prows = pair_rows(B, H, W, r);
 #define LAUNCH_PAIR_BWD(R, ROWS)                                                                               \
   hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, ROWS>), pair_grid(r, ROWS, B, H, W),                           \
                      dim3(64 * kPairWaves), (pair_smem<R, ROWS>(2)), s, im1, im2_warped, dldd, gout,            \
@@ -1228,7 +1250,7 @@ extern "C" int unflow_ternary_loss_warp_fwd(const float *im1, const float *im2, 
   }
   const double norm = norm_count > 0 ? (double)norm_count : (double)npix;
   const int r = max_distance;
-  const int prows = pair_rows(H, r);
+  const int prows = pair_rows(B, H, W, r);
   const dim3 pgrid = pair_grid(r, prows, B, H, W);
 #define LAUNCH_PAIR_WARP(R, ROWS)                                                                              \
   hipLaunchKernelGGL((ternary_fwd_pair_kernel<R, ROWS, true>), pgrid, dim3(64 * kPairWaves),                    \
@@ -1257,7 +1279,7 @@ extern "C" int unflow_ternary_loss_warp_bwd(const float *gray1, const float *gra
   if ((long long)B * H * W == 0) return UNFLOW_OK;
   hipStream_t s = as_stream(stream);
   const int r = max_distance;
-  const int prows = pair_rows(H, r);
+  const int prows = pair_rows(B, H, W, r);
 #define LAUNCH_PAIR_FUSED(R, ROWS)                                                                             \
   hipLaunchKernelGGL((ternary_bwd_pair_kernel<R, ROWS, true>), pair_grid(r, ROWS, B, H, W),                     \
                      dim3(64 * kPairWaves), (pair_smem<R, ROWS>(2)), s, gray1, gray2_warped, dldd, gout,        \
