@@ -6,7 +6,7 @@ import torch
 
 from . import _lib
 from .image_warp import image_warp
-from .ops import _dev, _ptr, _require_rank4, _stream
+from .ops import _dev, _on, _ptr, _require_rank4, _stream
 
 FLOW_SCALE = 5.0  # flownet.py:11
 
@@ -18,7 +18,7 @@ class _ResizeBilinear(torch.autograd.Function):
         _require_rank4(x, "images")
         B, h, w, C = x.shape
         out = torch.empty((B, height, width, C), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.load().unflow_resize_bilinear_fwd(_ptr(x), _ptr(out), B, h, w, height, width, C,
                                                               mult, _stream()))
         ctx.cfg = (h, w, mult)
@@ -30,7 +30,7 @@ class _ResizeBilinear(torch.autograd.Function):
         gout = gout.contiguous()
         B, H, W, C = gout.shape
         gin = torch.empty((B, h, w, C), device=gout.device, dtype=torch.float32)
-        with torch.cuda.device(gout.device):
+        with _on(gout.device):
             _lib.check(_lib.load().unflow_resize_bilinear_bwd(_ptr(gout), _ptr(gin), B, h, w, H, W, C, mult,
                                                               _stream()))
         return gin, None, None, None
@@ -61,7 +61,7 @@ def stacked_inputs(im1, im2, flow, train_all=False):
         warp = image_warp(im2, full)
         return torch.cat([im1, im2, full, warp, torch.abs(warp - im1)], dim=3)
     out = torch.empty((B, H, W, 14), device=im1.device, dtype=torch.float32)
-    with torch.cuda.device(im1.device):
+    with _on(im1.device):
         _lib.check(_lib.load().unflow_stacked_inputs_fwd(
             _ptr(im1), _ptr(im2), _ptr(flow.detach()), _ptr(out), B, H, W, flow.shape[1], flow.shape[2],
             mult, _stream()))

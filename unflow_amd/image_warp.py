@@ -9,7 +9,7 @@ tile/range/clip/gather x4/add_n graph; the gradients TF autodiff derives
 import torch
 
 from . import _lib
-from .ops import _check_flow, _dev, _ptr, _stream
+from .ops import _check_flow, _dev, _on, _ptr, _stream
 
 
 def image_warp_raw(im, flow):
@@ -17,7 +17,7 @@ def image_warp_raw(im, flow):
     _check_flow(im, flow)
     B, H, W, C = im.shape
     out = torch.empty_like(im)
-    with torch.cuda.device(im.device):
+    with _on(im.device):
         _lib.check(_lib.load().unflow_image_warp_fwd(_ptr(im), _ptr(flow), _ptr(out), B, H, W, C,
                                                      _stream()))
     return out
@@ -30,7 +30,7 @@ def image_warp_grad(grad, im, flow, want_im=True, want_flow=True):
     B, H, W, C = im.shape
     d_im = torch.empty_like(im) if want_im else None
     d_flow = torch.empty_like(flow) if want_flow else None
-    with torch.cuda.device(im.device):
+    with _on(im.device):
         _lib.check(_lib.load().unflow_image_warp_bwd(_ptr(grad), _ptr(im), _ptr(flow), _ptr(d_im),
                                                      _ptr(d_flow), B, H, W, C, _stream()))
     return d_im, d_flow

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .image_warp import image_warp
-from .ops import _check_flow, _dev, _ptr, _require_rank4, _stream, forward_warp
+from .ops import _check_flow, _dev, _on, _ptr, _require_rank4, _stream, forward_warp
 
 DISOCC_THRESH = 0.8  # losses.py:9
 
@@ -70,7 +70,7 @@ class DeferredReductions:
         c = (ctypes.c_float * max(n, 1))(*coeff)
         t = (ctypes.c_int * max(n, 1))(*term)
         w = (ctypes.c_float * max(n, 1))(*term_weight)
-        with torch.cuda.device(self.results.device):
+        with _on(self.results.device):
             _lib.check(_lib.load().unflow_reduce_plan_run(ctypes.byref(self.plan), c, t, w, _ptr(self.results), _ptr(total),
                                                           _ptr(per_term), _stream()))
 
@@ -103,7 +103,7 @@ class _FanOut(torch.autograd.Function):
             return live[0], None
         out = torch.empty_like(live[0])
         ptrs = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
-        with torch.cuda.device(out.device):
+        with _on(out.device):
             _lib.check(_lib.load().unflow_sum_tensors(ptrs, len(live), _ptr(out), out.numel(), _stream()))
         return out, None
 
@@ -127,7 +127,7 @@ def create_mask(tensor, paddings):
     mask = torch.empty((B, H, W, 1), device=tensor.device, dtype=torch.float32)
     if not mask.is_cuda:
         raise RuntimeError("create_mask: tensor must live on the GPU")
-    with torch.cuda.device(mask.device):
+    with _on(mask.device):
         _lib.check(_lib.load().unflow_create_mask(_ptr(mask), B, H, W, pt, pb, pl, pr, _stream()))
     return mask
 
@@ -149,7 +149,7 @@ def create_outgoing_mask(flow):
     _check_flow(None, flow)
     B, H, W, _ = flow.shape
     mask = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
-    with torch.cuda.device(flow.device):
+    with _on(flow.device):
         _lib.check(_lib.load().unflow_outgoing_mask(_ptr(flow), _ptr(mask), B, H, W, _stream()))
     return mask
 
@@ -165,7 +165,7 @@ def fb_occlusion(flow, flow_other_warped, mask_inout=None, mask_in=None):
     B, H, W, _ = flow.shape
     diff = torch.empty_like(flow)
     occ = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
-    with torch.cuda.device(flow.device):
+    with _on(flow.device):
         if mask_in is not None:
             if mask_inout is None:
                 raise ValueError("fb_occlusion: mask_in needs mask_inout to write the product to")
@@ -191,7 +191,7 @@ def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False, unwa
     B, H, W, _ = flow.shape
     warped = torch.empty_like(flow) if want_warped else None
     occ = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
-    with torch.cuda.device(flow.device):
+    with _on(flow.device):
         _lib.check(_lib.load().unflow_fb_occlusion_warp(
             _ptr(flow), _ptr(other), _ptr(warped), _ptr(occ),
             _ptr(mask_in if mask_in is not None else mask_inout), _ptr(mask_inout), B, H, W,
@@ -217,7 +217,7 @@ def sym_loss(mask, density_other, norm_count=0, thresh=DISOCC_THRESH):
         raise ValueError("sym_loss expects two [B,H,W,1] maps")
     loss = _loss_out(mask.device)
     ws = _workspace(B, H, W, mask.device)
-    with torch.cuda.device(mask.device):
+    with _on(mask.device):
         _lib.check(_lib.load().unflow_sym_loss_fwd(_ptr(mask), _ptr(density_other), float(thresh), _ptr(loss),
                                                    _ptr(ws), B, H, W, norm_count, _stream()))
     return _loss_result(loss, ws)
@@ -258,7 +258,7 @@ class _Charbonnier(torch.autograd.Function):
                 raise ValueError("mask channels must be 1 or match x")
         loss = _loss_out(x.device)
         ws = _workspace(B, H, W, x.device)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.load().unflow_charbonnier_fwd(
                 _ptr(x), _ptr(mask), mc, _ptr(loss), _ptr(ws), B, H, W, C, alpha, beta, epsilon,
                 truncate or 0.0, norm_count, _stream()))
@@ -273,7 +273,7 @@ class _Charbonnier(torch.autograd.Function):
         B, H, W, C = x.shape
         gout = gout.contiguous()
         dx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _on(x.device):
             _lib.check(_lib.load().unflow_charbonnier_bwd(
                 _ptr(x), _ptr(mask), mc, _ptr(gout), _ptr(dx), B, H, W, C, alpha, beta, epsilon,
                 truncate, norm_count, _stream()))
@@ -300,7 +300,7 @@ def _deltas(flow, order):
     B, H, W, _ = flow.shape
     K = 2 if order == 1 else 4
     du, dv, m = (torch.empty((B, H, W, K), device=flow.device, dtype=torch.float32) for _ in range(3))
-    with torch.cuda.device(flow.device):
+    with _on(flow.device):
         _lib.check(_lib.load().unflow_smoothness_deltas(_ptr(flow), _ptr(du), _ptr(dv), _ptr(m), B, H, W,
                                                         order, _stream()))
     return du, dv, m
@@ -326,7 +326,7 @@ class _SmoothnessLoss(torch.autograd.Function):
         B, H, W, _ = flow.shape
         loss = _loss_out(flow.device)
         ws = _workspace(B, H, W, flow.device)
-        with torch.cuda.device(flow.device):
+        with _on(flow.device):
             _lib.check(_lib.load().unflow_smoothness_loss_fwd(_ptr(flow), _ptr(loss), _ptr(ws), B, H, W,
                                                               order, norm_count, _stream()))
         ctx.save_for_backward(flow)
@@ -340,7 +340,7 @@ class _SmoothnessLoss(torch.autograd.Function):
         B, H, W, _ = flow.shape
         gout = gout.contiguous()
         d = torch.empty_like(flow)
-        with torch.cuda.device(flow.device):
+        with _on(flow.device):
             _lib.check(_lib.load().unflow_smoothness_loss_bwd(_ptr(flow), _ptr(gout), _ptr(d), B, H, W,
                                                               order, norm_count, _stream()))
         return d, None, None
@@ -365,7 +365,7 @@ def _gradient_delta(im1, im2_warped):
     if C != 3 or im2_warped.shape != im1.shape:
         raise ValueError("_gradient_delta expects two [B,H,W,3] images")
     diff = torch.empty((B, H, W, 6), device=im1.device, dtype=torch.float32)
-    with torch.cuda.device(im1.device):
+    with _on(im1.device):
         _lib.check(_lib.load().unflow_gradient_delta(_ptr(im1), _ptr(im2_warped), _ptr(diff), B, H, W,
                                                      _stream()))
     return diff
@@ -384,7 +384,7 @@ class _GradientLoss(torch.autograd.Function):
             raise ValueError("mask must have shape %s, got %s" % ((B, H, W, 1), tuple(mask.shape)))
         loss = _loss_out(im1.device)
         ws = _workspace(B, H, W, im1.device)
-        with torch.cuda.device(im1.device):
+        with _on(im1.device):
             _lib.check(_lib.load().unflow_gradient_loss_fwd(_ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss),
                                                             _ptr(ws), B, H, W, norm_count, _stream()))
         ctx.save_for_backward(im1, im2_warped, mask)
@@ -397,7 +397,7 @@ class _GradientLoss(torch.autograd.Function):
         B, H, W, _ = im1.shape
         gout = gout.contiguous()
         d = torch.empty_like(im2_warped)
-        with torch.cuda.device(im1.device):
+        with _on(im1.device):
             _lib.check(_lib.load().unflow_gradient_loss_bwd(_ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(gout),
                                                             _ptr(d), B, H, W, ctx.norm_count, _stream()))
         return None, d, None, None
@@ -425,7 +425,7 @@ class _TernaryLoss(torch.autograd.Function):
         loss = _loss_out(im1.device)
         dldd = torch.empty((B, H, W), device=im1.device, dtype=torch.float32)
         ws = _workspace(B, H, W, im1.device)
-        with torch.cuda.device(im1.device):
+        with _on(im1.device):
             _lib.check(_lib.load().unflow_ternary_loss_fwd(
                 _ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss), _ptr(dldd), _ptr(None), _ptr(ws),
                 B, H, W, max_distance, norm_count, _stream()))
@@ -439,7 +439,7 @@ class _TernaryLoss(torch.autograd.Function):
         B, H, W, _ = im1.shape
         gout = gout.contiguous()
         d = torch.empty_like(im2_warped)
-        with torch.cuda.device(im1.device):
+        with _on(im1.device):
             _lib.check(_lib.load().unflow_ternary_loss_bwd(
                 _ptr(im1), _ptr(im2_warped), _ptr(dldd), _ptr(gout), _ptr(d), B, H, W,
                 ctx.max_distance, _stream()))
@@ -462,7 +462,7 @@ class _TernaryWarped(torch.autograd.Function):
         loss = _loss_out(im1.device)
         dldd, gray1, gray2w = (torch.empty((B, H, W), device=im1.device, dtype=torch.float32) for _ in range(3))
         ws = _workspace(B, H, W, im1.device)
-        with torch.cuda.device(im1.device):
+        with _on(im1.device):
             _lib.check(_lib.load().unflow_ternary_loss_warp_fwd(
                 _ptr(im1), _ptr(im2), _ptr(flow_d), _ptr(mask), _ptr(loss), _ptr(dldd), _ptr(gray1), _ptr(gray2w),
                 _ptr(ws), B, H, W, max_distance, norm_count, _stream()))
@@ -476,7 +476,7 @@ class _TernaryWarped(torch.autograd.Function):
         B, H, W, _ = im2.shape
         gout = gout.contiguous()
         d_flow = torch.empty_like(flow)
-        with torch.cuda.device(im2.device):
+        with _on(im2.device):
             _lib.check(_lib.load().unflow_ternary_loss_warp_bwd(
                 _ptr(gray1), _ptr(gray2w), _ptr(dldd), _ptr(gout), _ptr(im2), _ptr(flow), _ptr(d_flow),
                 B, H, W, ctx.max_distance, _stream()))
@@ -511,7 +511,7 @@ def ternary_dist(im1, im2_warped, max_distance=1):
     loss = torch.empty((), device=im1.device, dtype=torch.float32)
     dist = torch.empty((B, H, W, 1), device=im1.device, dtype=torch.float32)
     ws = _workspace(B, H, W, im1.device)
-    with torch.cuda.device(im1.device):
+    with _on(im1.device):
         _lib.check(_lib.load().unflow_ternary_loss_fwd(
             _ptr(im1), _ptr(im2_warped), _ptr(mask), _ptr(loss), _ptr(None), _ptr(dist), _ptr(ws), B,
             H, W, max_distance, 0, _stream()))
@@ -529,7 +529,7 @@ def census_transform(im, max_distance=3, eps=0.9):
     if C != 3:
         raise ValueError("census_transform expects a [B,H,W,3] image, got %s" % (tuple(im.shape),))
     sig = torch.empty((B, H, W, 2), device=im.device, dtype=torch.int64)
-    with torch.cuda.device(im.device):
+    with _on(im.device):
         _lib.check(_lib.load().unflow_census_transform(_ptr(im), ctypes.c_void_p(sig.data_ptr()), B, H, W,
                                                        max_distance, eps, _stream()))
     return sig
@@ -546,7 +546,7 @@ def census_hamming(sig1, sig2, mask=None):
     total = torch.empty((), device=sig1.device, dtype=torch.int64)
     if mask is not None:
         mask = _dev(mask, "mask")
-    with torch.cuda.device(sig1.device):
+    with _on(sig1.device):
         _lib.check(_lib.load().unflow_census_hamming(
             ctypes.c_void_p(sig1.data_ptr()), ctypes.c_void_p(sig2.data_ptr()), _ptr(mask),
             ctypes.c_void_p(dist.data_ptr()), ctypes.c_void_p(total.data_ptr()), B, H, W, _stream()))

@@ -18,8 +18,33 @@ OP_NAMES = ['backward_warp', 'downsample', 'correlation', 'forward_warp']  # ops
 
 
 # --------------------------------------------------------------------------- plumbing
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """torch's current HIP stream of the current device as the ABI's stream argument (the raw handle: building a
+    torch.cuda.Stream object per launch is a few microseconds of the ~15 a launch costs from Python)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Here:
+    """Stands in for ``torch.cuda.device(d)`` when d is the current device already."""
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_HERE = _Here()
+
+
+def _on(device):
+    """``with _on(t.device):`` -- make t's device current for the launch; a no-op context in the usual case that it is
+    already (entering torch.cuda.device costs a get / set device pair per launch)."""
+    return _HERE if device.index == torch.cuda.current_device() else torch.cuda.device(device)
 
 
 def _ptr(t):
@@ -69,7 +94,7 @@ def _correlation_raw(first, second, materialize_padded, kernel_size, max_displac
     if materialize_padded:
         p0 = torch.empty(shapes["padded"], device=first.device, dtype=torch.float32)
         p1 = torch.empty(shapes["padded"], device=first.device, dtype=torch.float32)
-    with torch.cuda.device(first.device):
+    with _on(first.device):
         _lib.check(_lib.load().unflow_correlation_fwd(
             _ptr(first), _ptr(second), _ptr(out), _ptr(p0), _ptr(p1), B, C, H, W, kernel_size,
             max_displacement, pad, stride_1, stride_2, _stream()))
@@ -89,7 +114,7 @@ def correlation_grad(in_grad, original_input_0, original_input_1, padded_0=None,
         raise ValueError("input_grad has shape %s, expected %s" %
                          (tuple(in_grad.shape), shapes["correlation"]))
     g0, g1 = torch.empty_like(in0), torch.empty_like(in0)
-    with torch.cuda.device(in0.device):
+    with _on(in0.device):
         _lib.check(_lib.load().unflow_correlation_bwd(
             _ptr(in_grad), _ptr(in0), _ptr(in1), _ptr(padded_0), _ptr(padded_1), _ptr(g0), _ptr(g1),
             B, C, H, W, kernel_size, max_displacement, pad, stride_1, stride_2, _stream()))
@@ -112,7 +137,7 @@ def _backward_warp_raw(images, flows):
     _check_flow(images, flows)
     B, H, W, C = images.shape
     out = torch.empty_like(images)
-    with torch.cuda.device(images.device):
+    with _on(images.device):
         _lib.check(_lib.load().unflow_backward_warp_fwd(_ptr(images), _ptr(flows), _ptr(out), B, H,
                                                         W, C, _stream()))
     return out
@@ -125,7 +150,7 @@ def backward_warp_grad(grads, original_images, original_flows):
     _check_flow(images, flows)
     B, H, W, C = images.shape
     out = torch.empty_like(flows)
-    with torch.cuda.device(images.device):
+    with _on(images.device):
         _lib.check(_lib.load().unflow_backward_warp_bwd(_ptr(grads), _ptr(images), _ptr(flows),
                                                         _ptr(out), B, H, W, C, _stream()))
     return out
@@ -136,7 +161,7 @@ def _forward_warp_raw(flows):
     _check_flow(None, flows)
     B, H, W, _ = flows.shape
     out = torch.empty((B, H, W, 1), device=flows.device, dtype=torch.float32)
-    with torch.cuda.device(flows.device):
+    with _on(flows.device):
         _lib.check(_lib.load().unflow_forward_warp_fwd(_ptr(flows), _ptr(out), B, H, W, _stream()))
     return out
 
@@ -147,7 +172,7 @@ def forward_warp_grad(grads, original_flows):
     _check_flow(None, flows)
     B, H, W, _ = flows.shape
     out = torch.empty_like(flows)
-    with torch.cuda.device(flows.device):
+    with _on(flows.device):
         _lib.check(_lib.load().unflow_forward_warp_bwd(_ptr(grads), _ptr(flows), _ptr(out), B, H, W,
                                                        _stream()))
     return out
@@ -162,7 +187,7 @@ def downsample(images, scale=2):
     if scale <= 0 or H % scale != 0 or W % scale != 0:
         raise ValueError("Input height and width must be divisible by scale")
     out = torch.empty((B, H // scale, W // scale, C), device=images.device, dtype=torch.float32)
-    with torch.cuda.device(images.device):
+    with _on(images.device):
         _lib.check(_lib.load().unflow_downsample_fwd(_ptr(images), _ptr(out), B, H, W, C, scale,
                                                      _stream()))
     return out
@@ -232,7 +257,7 @@ def correlation_flip(volume, add=None, kernel_size=1, max_displacement=20, pad=2
     if (D, H, W) != tuple(want[1:]):
         raise ValueError("volume has shape %s, the attrs imply [B,%d,%d,%d]" % ((tuple(volume.shape),) + tuple(want[1:])))
     out = torch.empty_like(volume)
-    with torch.cuda.device(volume.device):
+    with _on(volume.device):
         _lib.check(_lib.load().unflow_correlation_flip(_ptr(volume), _ptr(add), _ptr(out), B, D, H, W, kernel_size,
                                                        max_displacement, pad, stride_1, stride_2, _stream()))
     return out
@@ -288,7 +313,7 @@ class _CorrelationFP16(torch.autograd.Function):
         out = torch.empty(shapes["correlation"], device=first.device, dtype=torch.float16)
         lib = _lib.load()
         fn = lib.unflow_correlation_fwd_f16_exact if exact else lib.unflow_correlation_fwd_f16
-        with torch.cuda.device(first.device):
+        with _on(first.device):
             _lib.check(fn(_hp(first), _hp(second), _hp(out), B, C, H, W, *attrs, _stream()))
         ctx.save_for_backward(first, second)
         ctx.attrs, ctx.exact = attrs, exact
@@ -314,7 +339,7 @@ def correlation_fp16_grad(in_grad, original_input_0, original_input_1, kernel_si
     g0, g1 = torch.empty_like(in0), torch.empty_like(in0)
     lib = _lib.load()
     fn = lib.unflow_correlation_bwd_f16_exact if exact else lib.unflow_correlation_bwd_f16
-    with torch.cuda.device(in0.device):
+    with _on(in0.device):
         _lib.check(fn(_hp(in_grad), _hp(in0), _hp(in1), _hp(g0), _hp(g1), B, C, H, W, *attrs, _stream()))
     return g0, g1
 
@@ -346,7 +371,7 @@ class _WarpFP16(torch.autograd.Function):
         B, H, W, C = images.shape
         out = torch.empty_like(images)
         fn = _lib.load().unflow_image_warp_fwd_f16 if clamp else _lib.load().unflow_backward_warp_fwd_f16
-        with torch.cuda.device(images.device):
+        with _on(images.device):
             _lib.check(fn(_hp(images), _hp(flows), _hp(out), B, H, W, C, _stream()))
         ctx.save_for_backward(images, flows)
         ctx.clamp = clamp
@@ -359,7 +384,7 @@ class _WarpFP16(torch.autograd.Function):
         B, H, W, C = images.shape
         d_flow = torch.empty_like(flows)
         fn = _lib.load().unflow_image_warp_bwd_flow_f16 if ctx.clamp else _lib.load().unflow_backward_warp_bwd_f16
-        with torch.cuda.device(images.device):
+        with _on(images.device):
             _lib.check(fn(_hp(grad), _hp(images), _hp(flows), _hp(d_flow), B, H, W, C, _stream()))
         return None, d_flow, None
 
@@ -385,7 +410,7 @@ def forward_warp_fp16(flows):
         raise ValueError("flows must have 2 channels")
     B, H, W, _ = flows.shape
     out = torch.empty((B, H, W, 1), device=flows.device, dtype=torch.float32)
-    with torch.cuda.device(flows.device):
+    with _on(flows.device):
         _lib.check(_lib.load().unflow_forward_warp_fwd_f16(_hp(flows), ctypes.c_void_p(out.data_ptr()), B, H, W, _stream()))
     return out
 

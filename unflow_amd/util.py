@@ -2,7 +2,7 @@
 import torch
 
 from . import _lib
-from .ops import _dev, _ptr, _require_rank4, _stream
+from .ops import _dev, _on, _ptr, _require_rank4, _stream
 from .ops import downsample as downsample_ops
 
 
@@ -21,7 +21,7 @@ def resize_area(images, size):
     if B * C > 0 and (H == 0 or W == 0):
         raise ValueError("input image must be of non-zero size")
     out = torch.empty((B, oh, ow, C), device=images.device, dtype=torch.float32)
-    with torch.cuda.device(images.device):
+    with _on(images.device):
         _lib.check(_lib.load().unflow_resize_area_fwd(_ptr(images), _ptr(out), B, H, W, C, oh, ow, _stream()))
     return out
 
