@@ -4,13 +4,22 @@ vector registers that only these blocks touch (the compiler is told through the 
 them); everything else of the kernel is C++.  Run after changing the register map:  python tools/gen_corr_bwd4_asm.py"""
 import os
 
-RING, MTS = 3, 8
+# B4_WAVES=16 (experiment, round 4): the same blocks for a SIXTEEN-wave workgroup -- a wave holds half of the channels of its
+# tiles (4 M-tiles: 48 accumulator registers, 128 VGPRs in all, four waves per SIMD) -> corr_bwd16_asm.inc, UNFLOW_BWD16_*
+W16 = os.environ.get("B4_WAVES", "8") == "16"
+PFX = "UNFLOW_BWD16_" if W16 else "UNFLOW_BWD4_"
+RING, MTS = 3, (4 if W16 else 8)
 ACS = 60                      # A image: floats per channel row (correlation_mfma.hip)
-AB = [136, 144]               # A fragment buffers: 8 registers each
-BB = [152, 155]               # B fragment buffers: 3 registers each
-ACC0 = 160                    # accumulators: v[160:255], tile (slot, m) at 160 + (slot * 8 + m) * 4
+if W16:
+    AB = [64, 68]             # A fragment buffers: 4 registers each
+    BB = [72, 75]             # B fragment buffers: 3 registers each
+    ACC0 = 80                 # accumulators: v[80:127]
+else:
+    AB = [136, 144]           # A fragment buffers: 8 registers each
+    BB = [152, 155]           # B fragment buffers: 3 registers each
+    ACC0 = 160                # accumulators: v[160:255], tile (slot, m) at 160 + (slot * 8 + m) * 4
 FIRST, LAST = AB[0], ACC0 + RING * MTS * 4 - 1
-assert LAST == 255
+assert LAST == (127 if W16 else 255)
 
 
 def acc(sl, m):
@@ -39,9 +48,10 @@ def reads(n):
 
 
 AG_BYTES = 8 * ACS * 4                      # a group of 8 channel rows of the A image
-A_STEP = 4 * AG_BYTES                        # LDS distance of a wave's consecutive A pieces (pieces p, p + 8: four groups on)
-T_STEP = 8 * 256 * 4                         # ... of its consecutive top-image pieces (8 pieces of 1 KiB on)
-TV = 158                                     # scratch registers (v158, v159) for a top-image piece's offset
+NW = 16 if W16 else 8
+A_STEP = (NW // 2) * AG_BYTES                # LDS distance of a wave's consecutive A pieces (pieces p, p + NW: NW / 2 groups on)
+T_STEP = NW * 256 * 4                        # ... of its consecutive top-image pieces (NW pieces of 1 KiB on)
+TV = 78 if W16 else 158                      # scratch registers (two) for a top-image piece's offset
 
 
 def dma_a(j):
@@ -86,7 +96,15 @@ def kstep(p, dma=None):
         if sl == 0 and not SPREAD:
             L += rd
         # (every group is guarded on its own and leaves EXEC complete: the MFMAs that follow need all lanes)
-        if dma == "A":
+        if dma == "A" and W16:   # sixteen waves: two A pieces and two top pieces per wave and row
+            if sl == 0:
+                L += ["s_cmp_eq_u32 %[fetch], 0", "s_cbranch_scc1 7f", "s_mov_b64 vcc, exec", "s_and_b64 exec, exec, %[amask]"] + dma_a(0) + dma_a(1) + ["s_mov_b64 exec, vcc", "7:"]
+            elif sl == 1:
+                L += ["s_cmp_eq_u32 %[fetch], 0", "s_cbranch_scc1 8f"] + dma_t(0) + ["8:"]
+        elif dma == "T" and W16:
+            if sl == 1:
+                L += ["s_cmp_eq_u32 %[t3], 0", "s_cbranch_scc1 8f"] + dma_t(1) + ["8:"]
+        elif dma == "A":
             if sl == 0:       # lanes that take part in an A piece: the same mask for the wave's four pieces
                 L += ["s_cmp_eq_u32 %[fetch], 0", "s_cbranch_scc1 7f", "s_mov_b64 vcc, exec", "s_and_b64 exec, exec, %[amask]"] + dma_a(0) + dma_a(1) + ["s_mov_b64 exec, vcc", "7:"]
             elif sl == 1:
@@ -140,27 +158,27 @@ def dump(sl):
 out = ["// GENERATED by tools/gen_corr_bwd4_asm.py -- do not edit.  Instruction blocks of corr_mfma_bwd4_kernel.",
        "// Register map: A fragments v[%d:%d] / v[%d:%d], B fragments v[%d:%d] / v[%d:%d], accumulators v[%d:%d]." % (
            AB[0], AB[0] + 7, AB[1], AB[1] + 7, BB[0], BB[0] + 2, BB[1], BB[1] + 2, ACC0, LAST),
-       "#define UNFLOW_BWD4_FIRST_FIXED_VGPR %d" % FIRST,
-       "#define UNFLOW_BWD4_CLOBBERS " + ", ".join('"v%d"' % r for r in range(FIRST, LAST + 1)),
+       "#define " + PFX + "FIRST_FIXED_VGPR %d" % FIRST,
+       "#define " + PFX + "CLOBBERS " + ", ".join('"v%d"' % r for r in range(FIRST, LAST + 1)),
        "// one K-step: wait for its fragments, 8 MFMAs per live ring slot (parity P buffers), the next K-step's 11 fragment",
        "// reads (other buffers) behind slot 0.  Operands: [live] s, [a_rd] [b0] [b1] [b2] v, [ia] [ib] i"]
 for p in (0, 1):
-    out.append("#define UNFLOW_BWD4_KSTEP_P%d \\\n%s" % (p, lit(kstep(p))))
+    out.append("#define " + PFX + "KSTEP_P%d \\\n%s" % (p, lit(kstep(p))))
 out.append("// K-step 0 of a row + the LDS-DMA of the next row's A image and top pieces 0, 1: [fetch] [a_m0] [asoff] [t_m0] [twoff] s,")
 out.append("// [amask] s (64 bit), [rin] [rtop] s (128 bit), [av0..3] [tb0] [tb1] v; clobbers vcc, m0")
-out.append("#define UNFLOW_BWD4_KSTEP0_DMA \\\n%s" % lit(kstep(0, "A")))
+out.append("#define " + PFX + "KSTEP0_DMA \\\n%s" % lit(kstep(0, "A")))
 out.append("// K-step 1 + top pieces 2, 3 ([t3] = 0: the wave has no fourth piece)")
-out.append("#define UNFLOW_BWD4_KSTEP1_DMA \\\n%s" % lit(kstep(1, "T")))
+out.append("#define " + PFX + "KSTEP1_DMA \\\n%s" % lit(kstep(1, "T")))
 out.append("// the sweep state one row further: [zero] [j0..2] [u0..2] [live] +s, [tmp] =&s, [aaddr] [br0..2] +v, [bu0..2] =v,")
 out.append("// [dstage] [dstep] [dwrap] [tmax] s, [oyl] v; clobbers vcc, scc")
-out.append("#define UNFLOW_BWD4_ROW_STEP \\\n%s" % lit(row_step()))
+out.append("#define " + PFX + "ROW_STEP \\\n%s" % lit(row_step()))
 out.append("// the first fragments of an item (into the parity-0 buffers)")
-out.append("#define UNFLOW_BWD4_FIRST_READS \\\n%s" % lit(reads(0)))
+out.append("#define " + PFX + "FIRST_READS \\\n%s" % lit(reads(0)))
 out.append("// a finished tile: accumulators of ring slot S to the epilogue image ([addr] v: byte address of the lane's")
 out.append("// (channel 4k, row, column) cell; + (m*16 + j) rows of 256 bytes), then zeroed")
 for sl in range(RING):
-    out.append("#define UNFLOW_BWD4_DUMP_S%d \\\n%s" % (sl, lit(dump(sl))))
-out.append("#define UNFLOW_BWD4_ZERO \\\n%s" % lit(["v_mov_b32 v%d, 0" % r for r in range(ACC0, LAST + 1)] + ["s_nop 1"]))
-path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unflow_amd", "csrc", "corr_bwd4_asm.inc")
+    out.append("#define " + PFX + "DUMP_S%d \\\n%s" % (sl, lit(dump(sl))))
+out.append("#define " + PFX + "ZERO \\\n%s" % lit(["v_mov_b32 v%d, 0" % r for r in range(ACC0, LAST + 1)] + ["s_nop 1"]))
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "unflow_amd", "csrc", "corr_bwd16_asm.inc" if W16 else "corr_bwd4_asm.inc")
 open(path, "w").write("\n".join(out) + "\n")
 print("wrote", path)
