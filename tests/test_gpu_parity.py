@@ -915,6 +915,15 @@ def test_fused_loss_glue_matches_composition(oracle_mod, dev):
     got = float(losses.sym_loss(m1, dens))
     want = float(losses.charbonnier_loss((1 - m1) - (dens < losses.DISOCC_THRESH).float()))
     np.testing.assert_allclose(got, want, rtol=1e-6)
+    # 16 bytes per lane when the pixel count allows it, one float otherwise: the same sum either way
+    for shape in ((1, 5, 7, 1), (3, 9, 13, 1), (1, 4, 9, 1)):
+        m = torch.from_numpy((rng.random(shape) < 0.6).astype(np.float32)).to(dev)
+        d = torch.from_numpy((rng.random(shape) * 0.5).astype(np.float32)).to(dev)
+        want = float(losses.charbonnier_loss((1 - m) - (d < losses.DISOCC_THRESH).float()))
+        np.testing.assert_allclose(float(losses.sym_loss(m, d)), want, rtol=1e-6, err_msg=str(shape))
+        tail = m.reshape(-1)[1:].reshape(1, -1, 1, 1), d.reshape(-1)[1:].reshape(1, -1, 1, 1)   # 4-byte aligned views
+        want = float(losses.charbonnier_loss((1 - tail[0]) - (tail[1] < losses.DISOCC_THRESH).float()))
+        np.testing.assert_allclose(float(losses.sym_loss(*tail)), want, rtol=1e-6, err_msg="view of %s" % (shape,))
     for mo in ("fb", "disocc", ""):
         fused = losses.compute_losses(T(im1, dev), T(im2, dev), ffw, fbw, border, mo, 2,
                                       terms=("ternary", "sym", "occ", "smooth_2nd"))
