@@ -67,6 +67,7 @@ def dma_t(j):
             "buffer_load_dwordx4 v%d, %%[rtop], 0 offen lds" % tv]
 
 
+PRIO = os.environ.get("B4_PRIO", "1") != "0" and not W16   # balanced issue priorities of the two waves of a SIMD
 SPREAD = os.environ.get("B4_SPREAD", "1") != "0"   # the next K-step's fragment reads one per MFMA gap (0: in one clump)
 
 
@@ -79,7 +80,14 @@ def kstep(p, dma=None):
     behind the first group left the matrix pipe idle.  A dead slot's group is skipped as a whole; its share of the
     reads is then issued in the skip path."""
     n = 1 - p
-    L = ["s_waitcnt lgkmcnt(0)"]
+    L = []
+    if PRIO:
+        # issue priority by progress: the two waves of a SIMD would otherwise be arbitrated by age, the older one running
+        # ahead and then waiting at the row barrier while the younger one works off its rest alone (stamps: a quarter of
+        # every row).  [pa] / [pb] fall along the row, the upper four waves' (bit 8 of [live]) one K-step later: the wave
+        # that is behind wins, at equal progress they take turns.
+        L += ["s_setprio %[pa]", "s_bitcmp0_b32 %[live], 8", "s_cbranch_scc1 10f", "s_setprio %[pb]", "10:"]
+    L += ["s_waitcnt lgkmcnt(0)"]
     rd = reads(n)
     share = {0: rd[:MTS], 1: rd[MTS:], 2: []} if SPREAD else {0: [], 1: [], 2: []}
     for sl in range(RING):
@@ -140,6 +148,54 @@ def row_step():
     return L
 
 
+def row_chunks(lb):
+    """row_step() as straight-line pieces that may stand between any two MFMAs (only the rare wrap of a slot -- one row
+    in 24 -- is a branch, and that piece is scalar; lb: its local labels).  Besides [bu*] (the address K-steps 1..5 of
+    the next row read the top image at) it leaves [bf*], the same with the lanes that have no valid dx' in K-step 0 on
+    the all-zero cell ([vfirst], a lane mask): what the first fragment reads of the next row take.  v{TV} holds the zero
+    cell's address."""
+    ch = [["s_add_u32 %[zero], %[zero], %[dstage]", "v_add_u32 %[aaddr], %[dstage], %[aaddr]", "v_mov_b32 v%d, %%[zero]" % TV]]
+    for sl in range(RING):
+        ch.append(["s_add_u32 %%[j%d], %%[j%d], 1" % (sl, sl), "s_cmp_lt_u32 %%[j%d], 24" % sl,
+                   "s_cselect_b32 %[tmp], %[dstep], %[dwrap]", "v_add_u32 %%[br%d], %%[tmp], %%[br%d]" % (sl, sl)])
+        ch.append(["s_cmp_lt_u32 %%[j%d], 24" % sl, "s_cbranch_scc1 %df" % (lb + sl),
+                   "s_mov_b32 %%[j%d], 0" % sl, "s_add_i32 %%[u%d], %%[u%d], 3" % (sl, sl), "s_bitset0_b32 %%[lvn], %d" % sl,
+                   "s_cmp_lt_i32 %%[u%d], %%[tmax]" % sl, "s_cbranch_scc0 %df" % (lb + sl), "s_bitset1_b32 %%[lvn], %d" % sl,
+                   "%d:" % (lb + sl)])
+        # rows j of a tile's life whose top-image row 20 + oyl - j lies in 0..20: 0 <= j - oyl <= 20
+        ch.append(["v_sub_u32 %%[bf%d], %%[j%d], %%[oyl]" % (sl, sl), "v_cmp_ge_u32 vcc, 20, %%[bf%d]" % sl,
+                   "v_cndmask_b32 %%[bu%d], v%d, %%[br%d], vcc" % (sl, TV, sl)])
+        ch.append(["s_and_b64 vcc, vcc, %[vfirst]", "s_nop 0", "v_cndmask_b32 %%[bf%d], v%d, %%[br%d], vcc" % (sl, TV, sl)])
+    return ch
+
+
+def kstep5_row():
+    """K-step 5 behind the row barrier WITH the sweep state's step to the next row between its MFMAs (slots 0, 1) and the
+    next row's first fragment reads between those of slot 2: executed as a block of its own behind the barrier, the
+    state's ~40 instructions met an empty matrix pipe in all eight waves at once (3.5 % of the kernel).  [live]: this
+    row's; the pieces a dead slot's group would have carried are issued in its skip path."""
+    p, n = 1, 0
+    L = []
+    if PRIO:
+        L += ["s_setprio %[pa]", "s_bitcmp0_b32 %[live], 8", "s_cbranch_scc1 10f", "s_setprio %[pb]", "10:"]
+    L += ["s_waitcnt lgkmcnt(0)"]
+    rd = ["ds_read_b32 v%d, %%[aaddr] offset:%d" % (AB[n] + m, m * 16 * ACS * 4) for m in range(MTS)]
+    rd += ["ds_read_b32 v%d, %%[bf%d] offset:%%[ib]" % (BB[n] + sl, sl) for sl in range(RING)]
+    rdp = [rd[0:2], rd[2:4], rd[4:6], rd[6:7], rd[7:8], rd[8:9], rd[9:10], rd[10:11]]
+    share = [{0: c[:7], 1: c[7:], 2: rdp} for c in (row_chunks(40), row_chunks(50))]   # [0]: between MFMAs, [1]: skip path
+    for sl in range(RING):
+        L += ["s_bitcmp0_b32 %%[live], %d" % sl, "s_cbranch_scc1 %df" % (sl + 1)]
+        for i, m in enumerate(mfmas(p, sl)):
+            L.append(m)
+            if i < len(share[0][sl]):
+                L += share[0][sl][i]
+        L += ["s_branch %df" % (sl + 4), "%d:" % (sl + 1)]
+        for c in share[1][sl]:
+            L += c
+        L += ["%d:" % (sl + 4)]
+    return L
+
+
 def dump(sl):
     # XDL write -> LDS data read of the same register needs software wait states (the compiler inserts them for its
     # own code; 8-pass MFMA: 11): 24 here, once per finished tile
@@ -169,9 +225,15 @@ out.append("// [amask] s (64 bit), [rin] [rtop] s (128 bit), [av0..3] [tb0] [tb1
 out.append("#define " + PFX + "KSTEP0_DMA \\\n%s" % lit(kstep(0, "A")))
 out.append("// K-step 1 + top pieces 2, 3 ([t3] = 0: the wave has no fourth piece)")
 out.append("#define " + PFX + "KSTEP1_DMA \\\n%s" % lit(kstep(1, "T")))
-out.append("// the sweep state one row further: [zero] [j0..2] [u0..2] [live] +s, [tmp] =&s, [aaddr] [br0..2] +v, [bu0..2] =v,")
-out.append("// [dstage] [dstep] [dwrap] [tmax] s, [oyl] v; clobbers vcc, scc")
-out.append("#define " + PFX + "ROW_STEP \\\n%s" % lit(row_step()))
+if W16:   # (the eight-wave kernel takes the state's step between the MFMAs of K-step 5: KSTEP5_ROW below)
+    out.append("// the sweep state one row further: [zero] [j0..2] [u0..2] [live] +s, [tmp] =&s, [aaddr] [br0..2] +v, [bu0..2] =v,")
+    out.append("// [dstage] [dstep] [dwrap] [tmax] s, [oyl] v; clobbers vcc, scc")
+    out.append("#define " + PFX + "ROW_STEP \\\n%s" % lit(row_step()))
+if not W16:
+    out.append("// K-step 5 + the sweep state one row further + the next row's first fragment reads: [live] s (this row's), [lvn] +s (the")
+    out.append("// next row's), [zero] [j0..2] [u0..2] +s, [tmp] =&s, [aaddr] [br0..2] +v, [bu0..2] [bf0..2] =&v, [dstage] [dstep] [dwrap]")
+    out.append("// [tmax] s, [vfirst] s (64 bit), [oyl] v, [ib] [pa] [pb] i; clobbers vcc, scc, v%d" % TV)
+    out.append("#define " + PFX + "KSTEP5_ROW \\\n%s" % lit(kstep5_row()))
 out.append("// the first fragments of an item (into the parity-0 buffers)")
 out.append("#define " + PFX + "FIRST_READS \\\n%s" % lit(reads(0)))
 out.append("// a finished tile: accumulators of ring slot S to the epilogue image ([addr] v: byte address of the lane's")

@@ -48,6 +48,14 @@ static_assert(A_PIECES % NWAVES == 0 && 4 * LDS_FLOATS <= 160 * 1024, "LDS budge
 // n*60 + (n>>3): the 8 channels of a group take the 8 banks = 0 mod 4 (60 = 28 mod 32), the next
 // group the banks = 1 mod 4, the second window column (+2 floats) the banks = 2, 3 mod 4.
 static_assert(ACS % 32 == 28, "A image bank pattern");
+// Issue priorities of the K-step blocks (s_setprio, corr_bwd4_asm.inc): falling along a row -- which begins behind
+// the row barrier with K-step 5 of the previous one --, the upper four waves' one K-step later than the lower four's.
+#ifndef UNFLOW_TUNE_PRIO_A
+#define UNFLOW_TUNE_PRIO_A 3, 2, 2, 1, 1, 0
+#define UNFLOW_TUNE_PRIO_B 3, 3, 2, 2, 1, 1
+#endif
+constexpr int prio_a(int q) { constexpr int p[6] = {UNFLOW_TUNE_PRIO_A}; return p[(q + 1) % 6]; }
+constexpr int prio_b(int q) { constexpr int p[6] = {UNFLOW_TUNE_PRIO_B}; return p[(q + 1) % 6]; }
 }  // namespace b2
 
 // Barriers of the row sweep, written out: the compiler's own wait-count insertion
@@ -77,7 +85,12 @@ static_assert(ACS % 32 == 28, "A image bank pattern");
 //   * the whole of sweep row w + 1 is fetched by 8 LDS-DMA instructions between the MFMA groups of K-steps 0, 1 of
 //     row w (M0 from one scalar add each, the row in the scalar offset / one v_add, one EXEC mask for the A pieces);
 //   * the sweep state (per ring slot: row of the tile's life, tile, live bit, the lanes' fragment addresses) moves
-//     one row further in ~27 scalar + 7 vector instructions (UNFLOW_BWD4_ROW_STEP);
+//     one row further in ~27 scalar + 18 vector instructions that stand BETWEEN the MFMAs of K-step 5, the one behind
+//     the row barrier (UNFLOW_BWD4_KSTEP5_ROW, round 4: as a block of its own behind the barrier it met an empty
+//     matrix pipe in all eight waves at once);
+//   * the two waves of a SIMD are kept level by issue priorities that fall along the row (s_setprio at the head of
+//     every K-step, prio_a / prio_b below): arbitrated by age, the older one ran ahead and waited for a quarter of
+//     every row at the barrier while the younger one worked off its rest alone (cycle stamps, tools/stamps.py);
 // 1.15 scalar + 0.55 vector instructions per MFMA in all (PMC), 0.99 ms per call = 0.71 of the peak, results
 // bit-equal to the second generation's.  The accumulators (96) and the double-buffered fragments (22 + 2 scratch)
 // live in FIXED registers v[136:255] that only the blocks touch: the blocks name them in their clobber lists, so
@@ -282,8 +295,9 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         }
       }
     }
+    const unsigned long long vfirst_mask = __builtin_amdgcn_ballot_w64(v_first);    // (the K-step 5 block's operand)
     const int b_lane = (((WRT1 ? oxl - k : k - oxl) * RW) + b_col + A_STAGE) * 4;     // bytes, + row, + K-step offset
-    // Sweep state, kept INCREMENTALLY (block UNFLOW_BWD4_ROW_STEP; the per-row recomputation of the second generation was
+    // Sweep state, kept INCREMENTALLY (block UNFLOW_BWD4_KSTEP5_ROW; the per-row recomputation of the second generation was
     // ~65 scalar + ~35 vector instructions, three of them quarter-rate multiplies).  Ring slot sl holds tile
     // t = 2u + ph, u = sl mod 3, through the 24 window rows that touch it: j = w - 4 ph + R - 8u = 0..23 is the row of
     // its life, and the slot passes on to u + 3 when j wraps.  A lane's top-image row is 20 + oyl - j: one image row up
@@ -360,12 +374,14 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
       }
       const unsigned fetch = ((more || !last_item) && !UNFLOW_TUNE_NODMA2) ? 1u : 0u;
       const int wn = more ? w + 1 : 0;
-      const unsigned live = (unsigned)__builtin_amdgcn_readfirstlane((int)sw_live);   // of THIS row: the state moves on behind the barrier
+      // of THIS row (the state moves on behind the barrier); bit 8: the upper four waves (the blocks' issue priorities)
+      const unsigned live = (unsigned)__builtin_amdgcn_readfirstlane((int)(sw_live | ((threadIdx.x >> 8) << 8)));
 
       // The matrix work of K-step q and the fragment reads of K-step q + 1 (K-step 5: the first fragments of row
       // w + 1) are ONE instruction block (corr_bwd4_asm.inc): the C++ around it only supplies the addresses.
       auto kstep_block = [&](auto Q) __attribute__((always_inline)) {
         constexpr int q = decltype(Q)::value, qn = (q + 1) % KSTEPS;
+        constexpr int pa = prio_a(q), pb = prio_b(q);
         constexpr int ia = 4 * S * qn * 4;
         constexpr int ib = (WRT1 ? KSTEPS - 1 - qn : qn) * (4 * RW * 4);
         unsigned b0 = sw_b[0], b1 = sw_b[1], b2 = sw_b[2];
@@ -382,10 +398,10 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         }
         const unsigned live_ = live, a_rd = sw_a;   // (asm operands must be locals of the lambda)
         if constexpr ((q & 1) == 0)
-          asm volatile(UNFLOW_BWD4_KSTEP_P0 : : [live] "s"(live_), [a_rd] "v"(a_rd), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [ia] "i"(ia), [ib] "i"(ib)
+          asm volatile(UNFLOW_BWD4_KSTEP_P0 : : [live] "s"(live_), [a_rd] "v"(a_rd), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [ia] "i"(ia), [ib] "i"(ib), [pa] "i"(pa), [pb] "i"(pb)
                        : "memory", "scc", UNFLOW_BWD4_CLOBBERS);
         else
-          asm volatile(UNFLOW_BWD4_KSTEP_P1 : : [live] "s"(live_), [a_rd] "v"(a_rd), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [ia] "i"(ia), [ib] "i"(ib)
+          asm volatile(UNFLOW_BWD4_KSTEP_P1 : : [live] "s"(live_), [a_rd] "v"(a_rd), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [ia] "i"(ia), [ib] "i"(ib), [pa] "i"(pa), [pb] "i"(pb)
                        : "memory", "scc", UNFLOW_BWD4_CLOBBERS);
       };
       // K-steps 0 and 1 with the LDS-DMA of row w + 1 between their MFMA groups (corr_bwd4_asm.inc)
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         const unsigned tb0 = (unsigned)fc.t_base[0], tb1 = (unsigned)fc.t_base[1];
         asm volatile(UNFLOW_BWD4_KSTEP0_DMA
                      : : [live] "s"(live_), [a_rd] "v"(a_rd), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [ia] "i"(ia), [ib] "i"(ib),
-                         [fetch] "s"(fetch_), [amask] "s"(amask), [a_m0] "s"(a_m0), [asoff] "s"(asoff), [rin] "s"(rin),
+                         [pa] "i"(prio_a(0)), [pb] "i"(prio_b(0)), [fetch] "s"(fetch_), [amask] "s"(amask), [a_m0] "s"(a_m0), [asoff] "s"(asoff), [rin] "s"(rin),
                          [av0] "v"(av0), [av1] "v"(av1), [av2] "v"(av2), [av3] "v"(av3),
                          [t_m0] "s"(t_m0), [twoff] "s"(twoff), [rtop] "s"(rtop), [tb0] "v"(tb0), [tb1] "v"(tb1)
                      : "memory", "scc", "vcc", "m0", UNFLOW_BWD4_CLOBBERS);   // (m0: the blocks write it in front of every LDS-DMA)
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         const unsigned tb2 = (unsigned)fc.t_base[2], tb3 = (unsigned)fc.t_base[3];
         asm volatile(UNFLOW_BWD4_KSTEP1_DMA
                      : : [live] "s"(live_), [a_rd] "v"(a_rd), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [ia] "i"(ia), [ib] "i"(ib),
-                         [fetch] "s"(fetch_), [t3] "s"(t3), [t_m0] "s"(t_m0), [twoff] "s"(twoff), [rtop] "s"(rtop), [tb2] "v"(tb2), [tb3] "v"(tb3)
+                         [pa] "i"(prio_a(1)), [pb] "i"(prio_b(1)), [fetch] "s"(fetch_), [t3] "s"(t3), [t_m0] "s"(t_m0), [twoff] "s"(twoff), [rtop] "s"(rtop), [tb2] "v"(tb2), [tb3] "v"(tb3)
                      : "memory", "scc", "m0", UNFLOW_BWD4_CLOBBERS);
       };
       // K-steps 3, 4: the pending tile store goes LAST among the vector-memory operations in front of the barrier
@@ -484,17 +500,26 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         int lv = UNFLOW_UNI(sw_live), zr = UNFLOW_UNI(sw_zero);
         const int tmax = UNFLOW_UNI(sw_tmax), ds0 = UNFLOW_UNI(dstage), ds1 = UNFLOW_UNI(dstep), ds2 = UNFLOW_UNI(dwrap);
 #undef UNFLOW_UNI
-        asm volatile(UNFLOW_BWD4_ROW_STEP
+        // K-step 5 of this row, the state's step and the first fragment reads of row w + 1 as ONE block (the state as a
+        // block of its own behind the barrier met an empty matrix pipe in all eight waves at once: 3.5 % of the kernel)
+        constexpr int ib = (WRT1 ? KSTEPS - 1 : 0) * (4 * RW * 4);
+        const unsigned live_ = live;
+        const unsigned long long vfirst_ = vfirst_mask;
+        unsigned bf0_, bf1_, bf2_;
+        asm volatile(UNFLOW_BWD4_KSTEP5_ROW
                      : [zero] "+s"(zr), [j0] "+s"(j0), [j1] "+s"(j1), [j2] "+s"(j2), [u0] "+s"(u0), [u1] "+s"(u1),
-                       [u2] "+s"(u2), [live] "+s"(lv), [tmp] "=&s"(tmp_), [aaddr] "+v"(sw_a), [br0] "+v"(sw_run[0]), [br1] "+v"(sw_run[1]),
-                       [br2] "+v"(sw_run[2]), [bu0] "=&v"(sw_b[0]), [bu1] "=&v"(sw_b[1]), [bu2] "=&v"(sw_b[2])
-                     : [dstage] "s"(ds0), [dstep] "s"(ds1), [dwrap] "s"(ds2), [tmax] "s"(tmax), [oyl] "v"(oyl_)
-                     : "vcc", "scc");
+                       [u2] "+s"(u2), [lvn] "+s"(lv), [tmp] "=&s"(tmp_), [aaddr] "+v"(sw_a), [br0] "+v"(sw_run[0]), [br1] "+v"(sw_run[1]),
+                       [br2] "+v"(sw_run[2]), [bu0] "=&v"(sw_b[0]), [bu1] "=&v"(sw_b[1]), [bu2] "=&v"(sw_b[2]),
+                       [bf0] "=&v"(bf0_), [bf1] "=&v"(bf1_), [bf2] "=&v"(bf2_)
+                     : [live] "s"(live_), [dstage] "s"(ds0), [dstep] "s"(ds1), [dwrap] "s"(ds2), [tmax] "s"(tmax), [oyl] "v"(oyl_),
+                       [vfirst] "s"(vfirst_), [ib] "i"(ib), [pa] "i"(prio_a(KSTEPS - 1)), [pb] "i"(prio_b(KSTEPS - 1))
+                     : "memory", "vcc", "scc", UNFLOW_BWD4_CLOBBERS);
         sw_j[0] = j0; sw_j[1] = j1; sw_j[2] = j2;
         sw_u[0] = u0; sw_u[1] = u1; sw_u[2] = u2;
         sw_live = (unsigned)lv; sw_zero = (unsigned)zr;
+      } else {
+        kstep_block(Int<KSTEPS - 1>{});   // last row of an item: no next row (the next item's first fragments: FIRST_READS)
       }
-      kstep_block(Int<KSTEPS - 1>{});
       // ---- a tile that ends on this row (not the last one: 4 t + 13 == w): its owners write it to ob
       // (free: its last image was stored two rows ago); the next barrier publishes it and the row after
       // that stores it inside its K-steps 3, 4.
