@@ -50,7 +50,9 @@ static_assert(A_PIECES % NWAVES == 0 && 4 * LDS_FLOATS <= 160 * 1024, "LDS budge
 static_assert(ACS % 32 == 28, "A image bank pattern");
 // Issue priorities of the K-step blocks (s_setprio, corr_bwd4_asm.inc): falling along a row -- which begins behind
 // the row barrier with K-step 5 of the previous one --, the upper four waves' one K-step later than the lower four's.
-#ifndef UNFLOW_TUNE_PRIO_A
+#ifdef UNFLOW_TUNE_PRIO_A                    // diagnostic: another pair of tables (tools/variants.sh)
+#define UNFLOW_TUNE_PRIO_TABLE
+#else
 #define UNFLOW_TUNE_PRIO_A 3, 2, 2, 1, 1, 0
 #define UNFLOW_TUNE_PRIO_B 3, 3, 2, 2, 1, 1
 #endif
@@ -484,8 +486,14 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
       // acknowledgement (microseconds under load) is not needed for anything -- only the DMA of the
       // next row must have landed.  (Every wave issues all four: each holds lanes of tile row 0.)
       UNFLOW_STAMP(rowc, 2);
+#if defined(UNFLOW_TUNE_NOROWBARRIER)        // timing only (races): the row barrier's round trip
+      asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+#elif defined(UNFLOW_TUNE_NOROWWAIT)         // timing only (races): neither the barrier nor the wait for the DMA
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
       if (store_tile >= 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       else UNFLOW_BARRIER_DMA();
+#endif
       UNFLOW_STAMP(rowc, 3);
       // every fragment of row w has been read: the sweep state moves on to row w + 1 (its stage is the other one)
       if (more) {
@@ -610,6 +618,15 @@ const char *tune_flags_correlation_bwd4() {
 #endif
 #ifdef UNFLOW_TUNE_OLD_BWD
          " UNFLOW_TUNE_OLD_BWD"
+#endif
+#ifdef UNFLOW_TUNE_NOROWBARRIER
+         " UNFLOW_TUNE_NOROWBARRIER"
+#endif
+#ifdef UNFLOW_TUNE_NOROWWAIT
+         " UNFLOW_TUNE_NOROWWAIT"
+#endif
+#ifdef UNFLOW_TUNE_PRIO_TABLE
+         " UNFLOW_TUNE_PRIO_TABLE"
 #endif
       ;
 }
