@@ -67,6 +67,7 @@ def dma_t(j):
             "buffer_load_dwordx4 v%d, %%[rtop], 0 offen lds" % tv]
 
 
+SOFTBAR = os.environ.get("B4_SOFTBAR", "1") != "0" and not W16   # the row barrier as an LDS arrival counter (kstep5_row)
 PRIO = os.environ.get("B4_PRIO", "1") != "0" and not W16   # balanced issue priorities of the two waves of a SIMD
 SPREAD = os.environ.get("B4_SPREAD", "1") != "0"   # the next K-step's fragment reads one per MFMA gap (0: in one clump)
 
@@ -184,6 +185,17 @@ def kstep5_row():
     rdp = [rd[0:2], rd[2:4], rd[4:6], rd[6:7], rd[7:8], rd[8:9], rd[9:10], rd[10:11]]
     share = [{0: c[:7], 1: c[7:], 2: rdp} for c in (row_chunks(40), row_chunks(50))]   # [0]: between MFMAs, [1]: skip path
     for sl in range(RING):
+        if SOFTBAR and sl == 1:
+            # The row barrier is an arrival counter in LDS ([bar]: its address; every wave adds 1 behind K-step 4, when
+            # its DMA pieces of the next row have landed and its last reads of this row's stage are on their way -- LDS
+            # serves a wave's operations in order).  Nothing in front of this point needs the other waves: the counter is
+            # read here, behind slot 0's MFMAs, and looked at in front of slot 2's, whose gaps carry the first reads of
+            # the next row's stage -- the s_barrier this replaces cost 4.9 % of the kernel with every wave standing still.
+            L += ["ds_read_b32 v%d, %%[bar]" % (TV + 1)]
+        if SOFTBAR and sl == 2:
+            L += ["s_waitcnt lgkmcnt(0)", "v_readfirstlane_b32 %%[tmp], v%d" % (TV + 1), "s_cmp_ge_u32 %[tmp], %[target]", "s_cbranch_scc1 61f",
+                  "60:", "ds_read_b32 v%d, %%[bar]" % (TV + 1), "s_waitcnt lgkmcnt(0)", "v_readfirstlane_b32 %%[tmp], v%d" % (TV + 1),
+                  "s_cmp_lt_u32 %[tmp], %[target]", "s_cbranch_scc1 60b", "61:"]
         L += ["s_bitcmp0_b32 %%[live], %d" % sl, "s_cbranch_scc1 %df" % (sl + 1)]
         for i, m in enumerate(mfmas(p, sl)):
             L.append(m)
@@ -232,7 +244,7 @@ if W16:   # (the eight-wave kernel takes the state's step between the MFMAs of K
 if not W16:
     out.append("// K-step 5 + the sweep state one row further + the next row's first fragment reads: [live] s (this row's), [lvn] +s (the")
     out.append("// next row's), [zero] [j0..2] [u0..2] +s, [tmp] =&s, [aaddr] [br0..2] +v, [bu0..2] [bf0..2] =&v, [dstage] [dstep] [dwrap]")
-    out.append("// [tmax] s, [vfirst] s (64 bit), [oyl] v, [ib] [pa] [pb] i; clobbers vcc, scc, v%d" % TV)
+    out.append("// [tmax] s, [vfirst] s (64 bit), [oyl] v, [ib] [pa] [pb] i, [bar] v [target] s (the row barrier's counter); clobbers vcc, scc, v%d, v%d" % (TV, TV + 1))
     out.append("#define " + PFX + "KSTEP5_ROW \\\n%s" % lit(kstep5_row()))
 out.append("// the first fragments of an item (into the parity-0 buffers)")
 out.append("#define " + PFX + "FIRST_READS \\\n%s" % lit(reads(0)))

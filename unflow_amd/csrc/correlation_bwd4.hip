@@ -41,9 +41,10 @@ constexpr int A_PIECES = CWS / 8 * 2;           // 32
 constexpr int A_STAGE = (CWS * ACS + 1 + 63) / 64 * 64;   // 7744 (odd groups start one float later)
 constexpr int STAGE2 = A_STAGE + T_STAGE;        // 15680 floats
 constexpr int LDS_FLOATS = 2 * STAGE2 + SW_OUT;  // 39552 floats = 158208 B
+constexpr int LDS_BYTES2 = 4 * LDS_FLOATS + 64;  // + the row barrier's arrival counter (one dword behind the images)
 constexpr int A_PER_WAVE = A_PIECES / NWAVES;   // 4
 constexpr int T_PER_WAVE = (T_PIECES + NWAVES - 1) / NWAVES;   // 4 (wave 7: 3)
-static_assert(A_PIECES % NWAVES == 0 && 4 * LDS_FLOATS <= 160 * 1024, "LDS budget");
+static_assert(A_PIECES % NWAVES == 0 && LDS_BYTES2 <= 160 * 1024, "LDS budget");
 // A fragment (ds_read_b32, lanes 0..31 = 16 channels x 2 window columns): channel n sits at
 // n*60 + (n>>3): the 8 channels of a group take the 8 banks = 0 mod 4 (60 = 28 mod 32), the next
 // group the banks = 1 mod 4, the second window column (+2 floats) the banks = 2, 3 mod 4.
@@ -90,6 +91,9 @@ constexpr int prio_b(int q) { constexpr int p[6] = {UNFLOW_TUNE_PRIO_B}; return 
 //     one row further in ~27 scalar + 18 vector instructions that stand BETWEEN the MFMAs of K-step 5, the one behind
 //     the row barrier (UNFLOW_BWD4_KSTEP5_ROW, round 4: as a block of its own behind the barrier it met an empty
 //     matrix pipe in all eight waves at once);
+//   * the ROW BARRIER is an arrival counter in LDS instead of s_barrier (round 4): a wave adds 1 behind K-step 4 and looks
+//     at the counter inside K-step 5, in front of its first reads of the next row's stage; the MFMAs of K-step 5 need
+//     nothing from the other waves and run while the last ones arrive (-1.6 to -1.9 %, bit-equal);
 //   * the two waves of a SIMD are kept level by issue priorities that fall along the row (s_setprio at the head of
 //     every K-step, prio_a / prio_b below): arbitrated by age, the older one ran ahead and waited for a quarter of
 //     every row at the barrier while the younger one worked off its rest alone (cycle stamps, tools/stamps.py);
@@ -259,6 +263,11 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
 #pragma unroll
   for (int j = 0; j < T_PER_WAVE; ++j) issue_t(fc, j, 0, lds);
 
+  // The ROW BARRIER is an arrival counter in LDS, not s_barrier: a wave adds 1 behind K-step 4 of a row and looks at the
+  // counter inside K-step 5 (UNFLOW_BWD4_KSTEP5_ROW), in front of its first reads of the next row's stage -- the MFMAs of
+  // K-step 5 need nothing from the other waves and run while the last ones arrive.  It never wraps (8 per row).
+  const unsigned bar_addr = lds0 + LDS_FLOATS * 4;
+  if (threadIdx.x == 0) lds[LDS_FLOATS] = 0.f;
   UNFLOW_BARRIER_DMA();          // row 0 of the first item has landed
 #ifdef UNFLOW_TUNE_STAMPS
   int stamp_slot = -1;           // workgroups 0..3 and 128..131, waves 0 and 4 (SIMD partners), WRT1 launch, first item
@@ -491,8 +500,21 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
 #elif defined(UNFLOW_TUNE_NOROWWAIT)         // timing only (races): neither the barrier nor the wait for the DMA
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
-      if (store_tile >= 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else UNFLOW_BARRIER_DMA();
+      {
+        // ARRIVAL at the row barrier's counter: this wave's DMA pieces of row w + 1 have landed (vmcnt counts loads,
+        // LDS-DMA and stores together, in issue order: the four tile stores of a storing row are its youngest operations
+        // and nothing waits for their acknowledgement), its last reads of row w's stage are in LDS's queue ahead of the
+        // add (LDS serves a wave's operations in order).  One lane adds 1.  (Arriving earlier -- inside K-step 4, behind
+        // its last fragment read -- measured the same: what is left of the barrier is the slowest wave of the row.)
+        const unsigned one_ = 1u, bar_ = bar_addr;
+        if (store_tile >= 0)
+          asm volatile("s_waitcnt vmcnt(4)\n\ts_mov_b64 vcc, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, vcc" : : "v"(bar_), "v"(one_) : "memory", "vcc");
+        else
+          asm volatile("s_waitcnt vmcnt(0)\n\ts_mov_b64 vcc, exec\n\ts_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, vcc" : : "v"(bar_), "v"(one_) : "memory", "vcc");
+        // the last row of an item keeps the hardware barrier: the next item's first fragments are read by a block of
+        // their own (FIRST_READS), and the item-end epilogue works with s_barrier anyway
+        if (!more) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
 #endif
       UNFLOW_STAMP(rowc, 3);
       // every fragment of row w has been read: the sweep state moves on to row w + 1 (its stage is the other one)
@@ -513,6 +535,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
         constexpr int ib = (WRT1 ? KSTEPS - 1 : 0) * (4 * RW * 4);
         const unsigned live_ = live;
         const unsigned long long vfirst_ = vfirst_mask;
+        const unsigned bar_target = (unsigned)__builtin_amdgcn_readfirstlane(NWAVES * (rowc + 1));   // every wave has arrived for this row
         unsigned bf0_, bf1_, bf2_;
         asm volatile(UNFLOW_BWD4_KSTEP5_ROW
                      : [zero] "+s"(zr), [j0] "+s"(j0), [j1] "+s"(j1), [j2] "+s"(j2), [u0] "+s"(u0), [u1] "+s"(u1),
@@ -520,7 +543,8 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
                        [br2] "+v"(sw_run[2]), [bu0] "=&v"(sw_b[0]), [bu1] "=&v"(sw_b[1]), [bu2] "=&v"(sw_b[2]),
                        [bf0] "=&v"(bf0_), [bf1] "=&v"(bf1_), [bf2] "=&v"(bf2_)
                      : [live] "s"(live_), [dstage] "s"(ds0), [dstep] "s"(ds1), [dwrap] "s"(ds2), [tmax] "s"(tmax), [oyl] "v"(oyl_),
-                       [vfirst] "s"(vfirst_), [ib] "i"(ib), [pa] "i"(prio_a(KSTEPS - 1)), [pb] "i"(prio_b(KSTEPS - 1))
+                       [vfirst] "s"(vfirst_), [ib] "i"(ib), [pa] "i"(prio_a(KSTEPS - 1)), [pb] "i"(prio_b(KSTEPS - 1)),
+                       [bar] "v"(bar_addr), [target] "s"(bar_target)
                      : "memory", "vcc", "scc", UNFLOW_BWD4_CLOBBERS);
         sw_j[0] = j0; sw_j[1] = j1; sw_j[2] = j2;
         sw_u[0] = u0; sw_u[1] = u1; sw_u[2] = u2;
@@ -594,7 +618,7 @@ int corr_mfma_bwd(const float *topdiff, const float *in0, const float *in1, floa
     // per gradient
     const int nitems = nbx * nch * S * B;
     const int nwg = nitems < num_cus() ? nitems : num_cus();
-    const size_t smem2 = sizeof(float) * b2::LDS_FLOATS;
+    const size_t smem2 = b2::LDS_BYTES2;
     if (int rc = reserve_lds<corr_mfma_bwd4_kernel<false>>(smem2, "correlation_bwd (mfma)")) return rc;
     if (int rc = reserve_lds<corr_mfma_bwd4_kernel<true>>(smem2, "correlation_bwd (mfma)")) return rc;
     hipLaunchKernelGGL(corr_mfma_bwd4_kernel<false>, dim3(nwg), dim3(NTHREADS), smem2, s, topdiff, in1, g0, C, H, W, nbx, nch, nitems);
