@@ -31,7 +31,7 @@ import sys
 #   FWD2_NODMA=1   timing only: no LDS-DMA at all
 #   FWD2_FULL=1    experiment: the FULL window per workgroup -- six N-tile rows, 36 accumulator tiles per
 #                  wave, 256 registers, ONE workgroup per CU -- instead of two half-window workgroups
-KNOBS = {k: os.environ.get("FWD2_" + k, "") for k in ("STAMPS", "NODMA", "FULL", "OUT")}
+KNOBS = {k: os.environ.get("FWD2_" + k, "") for k in ("STAMPS", "NODMA", "FULL", "OUT", "PRIO")}
 FULL = bool(KNOBS["FULL"])
 
 # ---- LDS layout of a stage (floats), shared with correlation_fwd2.hip through the generated constants
@@ -144,6 +144,8 @@ def kstep(j, base, dma, wait, spec, reads=True):
              "s_sub_u32 s94, s90, s92", "s_add_u32 %[accb], %[accb], s94"]
     else:
         L = ["s_waitcnt vmcnt(%d) lgkmcnt(0)" % wait, "s_barrier"]
+    if KNOBS["PRIO"]:      # experiment: an issue priority per K-step of the group of four, e.g. FWD2_PRIO=3210
+        L.append("s_setprio %d" % int(KNOBS["PRIO"][j]))
     if reads:
         L.append(read_a(1 - p, nstage))
     for r in range(NROW):
