@@ -91,6 +91,26 @@ def test_correlation_is_deterministic_cfg2(dev):
         assert torch.equal(a, g0) and torch.equal(b, g1)
 
 
+def test_correlation_gradients_do_not_depend_on_the_item_schedule(dev):
+    """A persistent workgroup of the backward walks several items at B = 32 and hands the last tiles of one item to the
+    first rows of the next one's sweep (deferred end tiles, correlation_bwd4.hip); at B = 2 every workgroup has one item
+    and ends it synchronously.  Both paths add the same products in the same order: the gradients of two pairs must
+    not change by a bit when the batch holds sixteen copies of them -- nor may the forward."""
+    from unflow_amd import ops
+    g = gen(dev, 77)
+    f0 = torch.randn((2, C8, H8, W8), device=dev, generator=g)
+    f1 = torch.randn((2, C8, H8, W8), device=dev, generator=g)
+    top = torch.randn((2, 441, H8, W8), device=dev, generator=g)
+    c_small = ops.correlation(f0, f1)
+    g0_small, g1_small = ops.correlation_grad(top, f0, f1)
+    rep = lambda t: t.repeat(16, 1, 1, 1).contiguous()
+    c_big = ops.correlation(rep(f0), rep(f1))
+    g0_big, g1_big = ops.correlation_grad(rep(top), rep(f0), rep(f1))
+    for small, big, name in ((c_small, c_big, "forward"), (g0_small, g0_big, "gradient 0"), (g1_small, g1_big, "gradient 1")):
+        assert torch.equal(big, rep(small)), name
+    assert float(g0_small.abs().max()) > 0 and float(g1_small.abs().max()) > 0
+
+
 def test_correlation_full_size_sample_vs_oracle(oracle_mod, dev):
     """One full-size pair against the CPU oracle (about 3 s of CPU)."""
     from unflow_amd import ops

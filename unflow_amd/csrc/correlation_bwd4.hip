@@ -557,7 +557,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
       // that stores it inside its K-steps 3, 4.
       store_tile = dumped;
       dumped = -1;
-#ifdef UNFLOW_TUNE_NOSTORE
+#if defined(UNFLOW_TUNE_NOSTORE) || defined(UNFLOW_TUNE_NS_LOOP)
       if (C < 0)                               // diagnostic: never true at run time, opaque to the compiler
 #endif
       if (more) {
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
           dumped = t;
         }
       }
-#ifdef UNFLOW_TUNE_NOSTORE
+#if defined(UNFLOW_TUNE_NOSTORE) || defined(UNFLOW_TUNE_NS_END)
       if (C > 0) continue;
 #endif
       if (!more) {
@@ -651,6 +651,12 @@ const char *tune_flags_correlation_bwd4() {
 #endif
 #ifdef UNFLOW_TUNE_PRIO_TABLE
          " UNFLOW_TUNE_PRIO_TABLE"
+#endif
+#ifdef UNFLOW_TUNE_NS_LOOP
+         " UNFLOW_TUNE_NS_LOOP"
+#endif
+#ifdef UNFLOW_TUNE_NS_END
+         " UNFLOW_TUNE_NS_END"
 #endif
       ;
 }
