@@ -359,7 +359,11 @@ __global__ __launch_bounds__(NTHREADS, 2) __attribute__((amdgpu_num_vgpr(UNFLOW_
       // The store and the two wait states gfx950 needs before anything may overwrite its data registers (a store-data
       // hazard the compiler does not cover for an SGPR soffset: tools/ubench/store_data_hazard.hip) are ONE statement,
       // so that nothing can be scheduled in between.
+#ifdef UNFLOW_TUNE_NOGLOBAL     // timing only: the tile pieces are read and scaled, not stored (OOB offset: the store is issued and dropped)
+      asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(OOB), "s"(rout), "s"(soff) : "memory");
+#else
       asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rout), "s"(soff) : "memory");
+#endif
     };
 
     int store_tile = -1;         // tile whose image in ob is stored during this row      (workgroup-uniform)
@@ -651,6 +655,9 @@ const char *tune_flags_correlation_bwd4() {
 #endif
 #ifdef UNFLOW_TUNE_PRIO_TABLE
          " UNFLOW_TUNE_PRIO_TABLE"
+#endif
+#ifdef UNFLOW_TUNE_NOGLOBAL
+         " UNFLOW_TUNE_NOGLOBAL"
 #endif
 #ifdef UNFLOW_TUNE_NS_LOOP
          " UNFLOW_TUNE_NS_LOOP"
