@@ -189,6 +189,9 @@ def test_seeded_extensions(seeded, dev):
     # while the DMA already runs a row ahead (the row barrier sits inside the row)
     ((130, 128, 4, 8), dict()),
     ((66, 256, 5, 8), dict()),
+    # ... and with TALL row classes (14 rows: the row barrier is the arrival counter in LDS on 13 of them, the epilogue
+    # image is recycled in-loop) on workgroups that walk two items: 280 items on 256 CUs
+    ((14, 128, 28, 160), dict()),
     # C % 128 == 0 but not a power of two: the tile stores divide by C instead of multiplying by 1/C
     ((2, 384, 13, 20), dict()),
     # the forward's ring of four 4-channel stages (corr_fwd2_kernel, C % 16 == 0 and W % 4 == 0): one group of four K-steps
