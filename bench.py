@@ -401,7 +401,7 @@ def loss_kernels_roofline(wl, copy_gbs):
     """The loss kernels of the step, each against the ceiling that bounds it (in-run HIP-event times at the step's batch):
       * soft census forward / backward, fused with the warp (ternary_*_pair_kernel<3,16,true>): VALU ISSUE.  A wave walks
         19 rows x 24 pair taps x 3 transcendentals (8 issue cycles each) among `valu_insts_per_wave` vector instructions
-        (4 cycles each; the count is the PMC's SQ_INSTS_VALU / SQ_WAVES of profiles/r03_pmc_loss.json); floor = that
+        (4 cycles each; the count is the PMC's SQ_INSTS_VALU / SQ_WAVES of profiles/r04_pmc_loss.json); floor = that
         issue time over 1024 SIMDs at 2.4 GHz.  `pmc_valu_issue_frac` is the measured SQ_ACTIVE_INST_VALU share.
       * forward_warp: LDS integer atomics.  floor = 81 taps per source pixel as wave instructions x 5.3 cycles (the
         conflict-free ds_add_u32 rate per CU, profiles/ubench_lds_atomic.txt) over 256 CUs.
@@ -412,7 +412,7 @@ def loss_kernels_roofline(wl, copy_gbs):
     npx = B * H * W
     ffw, fbw = wl.flow_fw.detach(), wl.flow_bw.detach()
     pmc = {}
-    path = os.path.join(ROOT, "profiles", "r04_pmc_loss.json")      # (the loss kernels are round 3's: either round's counters)
+    path = os.path.join(ROOT, "profiles", "r04_pmc_loss.json")      # (collected at the end of round 4; round 3's as a fallback)
     if not os.path.exists(path):
         path = os.path.join(ROOT, "profiles", "r03_pmc_loss.json")
     if os.path.exists(path):
