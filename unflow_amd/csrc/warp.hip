@@ -637,6 +637,18 @@ __device__ inline Window splat_window(int src_x, int src_y, float2 f, int H, int
 // The Gaussian is separable: 9 + 9 instead of 81 exponentials per pixel.
 constexpr int kSX = 64, kSY = 16;          // source tile
 constexpr int kWinCells = 15360;           // LDS window capacity (60 KB)
+// image gradient of image_warp: columns and rows of a workgroup's pixel tile and ints of LDS for its two windows,
+// for three channels and for one or two
+#ifdef UNFLOW_TUNE_IM3
+constexpr int kIm3Cols = UNFLOW_TUNE_IM3_COLS, kIm3Rows = UNFLOW_TUNE_IM3_ROWS, kIm3Win = UNFLOW_TUNE_IM3_WIN;
+#else
+constexpr int kIm3Cols = 32, kIm3Rows = 16, kIm3Win = 10240;
+#endif
+#ifdef UNFLOW_TUNE_IM2
+constexpr int kIm2Cols = UNFLOW_TUNE_IM2_COLS, kIm2Rows = UNFLOW_TUNE_IM2_ROWS, kIm2Win = UNFLOW_TUNE_IM2_WIN;
+#else
+constexpr int kIm2Cols = 32, kIm2Rows = 16, kIm2Win = 7680;
+#endif
 constexpr int kWW = 96, kWH = 48;          // fallback window when the bounding box does not fit
 constexpr int kSplatThreads = kSX * kSY;   // one lane per source pixel: 16 waves, two workgroups (120 KB LDS) fill a CU
 constexpr float kFix = 2097152.f;          // 2^21
@@ -1035,7 +1047,7 @@ __global__ __launch_bounds__(kBlock) void downsample_px_kernel(const float *__re
 }
 
 // Image gradient of image_warp (the scatter-add TF derives from tf.gather), LDS-privatised.
-// One workgroup owns a 64x16 tile of pixels; the cells its 2x2 taps touch form a bounding
+// One workgroup owns a tile of pixels (32 x 16); the cells its 2x2 taps touch form a bounding
 // box that -- for a coherent flow -- is little larger than the tile.  The taps are added
 // into an LDS window of that box and the window is flushed with global atomics over
 // CONTIGUOUS rows of ww*C floats -- instead of 4*C strided global atomics per pixel.  Tiles
@@ -1049,31 +1061,41 @@ __global__ __launch_bounds__(kBlock) void downsample_px_kernel(const float *__re
 // most 4 * 1024 adds, so neither sum leaves 32 bits; a contribution is represented to 2^-38 of the
 // tile's largest gradient (f32 itself resolves 2^-24 of a value) and integer addition makes the
 // window sum independent of the order of the adds.
-// TY: rows of the pixel tile (64 x TY, one lane per pixel).  Three channels take 64 x 8 tiles: the box of a
-// 64 x 16 tile (1.5 .. 2 thousand pixels at the flow gradients of the KITTI-shaped workload) times three
-// channels times two integer windows does not fit the 60 KB.
-template <int C, int TY>
-__global__ __launch_bounds__(kSX * TY) void image_warp_bwd_im_tiled_kernel(const float *__restrict__ grad,
+// TX x TY: the workgroup's pixel tile, one lane per pixel; WIN: ints of LDS for its two windows.  The box of a tile is
+// (TX + d) x (TY + d) pixels with d the spread of the flow inside the tile, and d grows with the tile's diameter: at
+// the flow gradients of the KITTI-shaped workload a 64 x 8 tile spreads to ~2.5 thousand cells (5 per pixel), a
+// 32 x 16 tile to ~1.2 thousand (2.4 per pixel) -- fewer cells to zero and to flush, and a window that fits in 40 KB
+// (three channels) or 30 KB (one, two) instead of 60, so that four workgroups of eight waves fill every wave slot of
+// a CU (the kernel needs 30 VGPRs: the window is what set its occupancy).  Round 4, tools/iwim_variant.py at
+// 32 x 384 x 1280: three channels 64 x 8 / 60 KB 0.454 ms, 32 x 16 / 40 KB 0.335 ms (32 x 32 / 60 KB and 32 x 8 / 30 KB
+// the same; 32 x 8 / 20 KB 0.61: boxes no longer fit); two channels 64 x 16 / 60 KB 0.263, 32 x 16 / 30 KB 0.236 ms.
+// A window too small is expensive (the strided float atomics of the fallback: 64 x 8 / 40 KB took 1.49 ms).
+// Timing-only builds of the 32 x 16 form: without the LDS atomics 0.205 ms, without the flush's global atomics 0.309.
+// The tap coordinates come from clamp_tap_coords: un-flattening clamp_taps' 64-bit indices cost four 64-bit
+// divisions per pixel, 40 % of the kernel's vector instructions (0.484 -> 0.454 ms).
+template <int C, int TX, int TY, int WIN>
+__global__ __launch_bounds__(TX * TY) void image_warp_bwd_im_tiled_kernel(const float *__restrict__ grad,
                                                                                 const float2 *__restrict__ flow,
                                                                                 float *__restrict__ d_im, int H,
                                                                                 int W) {
-  __shared__ int win[kWinCells];               // [hi window | lo window], kWinCells / 2 cells each
+  __shared__ int win[WIN];                     // [hi window | lo window], WIN / 2 cells each
   __shared__ int box[4];
   __shared__ unsigned gmax_bits;
-  constexpr int kCells = kWinCells / 2;
-  constexpr int NT = kSX * TY;
-  const int x0 = blockIdx.x * kSX, y0 = blockIdx.y * TY;
+  constexpr int kCells = WIN / 2;
+  constexpr int NT = TX * TY;
+  static_assert(NT % 64 == 0 && NT <= 1024, "whole waves; fixed-point headroom assumes <= 1024 source pixels per window");
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
   const long long item = (long long)blockIdx.z * H * W;
-  const int sx = x0 + (threadIdx.x % kSX), sy = y0 + threadIdx.x / kSX;
+  const int sx = x0 + (threadIdx.x % TX), sy = y0 + threadIdx.x / TX;
   const bool live = sx < W && sy < H;
   int tx0 = 0, tx1 = 0, ty0 = 0, ty1 = 0;
   float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f, g[C];
   float gabs = 0.f;
   if (live) {
     const long long p = item + (long long)sy * W + sx;
-    const ClampTaps t = clamp_taps(sx, sy, flow[p], H, W);
-    tx0 = (int)(t.ia % W); ty0 = (int)(t.ia / W);     // clamped tap coordinates
-    tx1 = (int)(t.id % W); ty1 = (int)(t.id / W);
+    const ClampCoords t = clamp_tap_coords(sx, sy, flow[p], H, W);
+    tx0 = t.x0; ty0 = t.y0;
+    tx1 = t.x1; ty1 = t.y1;
     wa = (1.f - t.xw) * (1.f - t.yw); wb = (1.f - t.xw) * t.yw;
     wc = t.xw * (1.f - t.yw); wd = t.xw * t.yw;
 #pragma unroll
@@ -1140,6 +1162,50 @@ __global__ __launch_bounds__(kSX * TY) void image_warp_bwd_im_tiled_kernel(const
     win[kCells + i] = 0;
   }
   __syncthreads();
+#ifdef UNFLOW_TUNE_IM_MERGE
+  {
+    // In a coherent flow the right-hand taps of a pixel are the left-hand taps of its right neighbour.  A lane whose
+    // left neighbour (DPP row_shr:1, rows of 16 lanes lie inside one tile row) has its taps c, d on this lane's cells
+    // a, b adds the neighbour's two integer pairs to its own and the neighbour skips those atomics: 2 cells per pixel
+    // and channel instead of 4 wherever floor(flow) does not change between the two.  Integer sums: bit-equal.
+    static_assert(TX % 16 == 0, "a DPP row must lie inside one tile row");
+    const int ka = live ? ((ty0 - wy0) * ww + (tx0 - wx0)) * C : -1, kb = live ? ((ty1 - wy0) * ww + (tx0 - wx0)) * C : -1;
+    const int kc = live ? ((ty0 - wy0) * ww + (tx1 - wx0)) * C : -3, kd = live ? ((ty1 - wy0) * ww + (tx1 - wx0)) * C : -3;
+    const int lkc = __builtin_amdgcn_update_dpp(-2, kc, 0x111, 0xf, 0xf, false);     // row_shr:1
+    const int lkd = __builtin_amdgcn_update_dpp(-2, kd, 0x111, 0xf, 0xf, false);
+    const int take = (lkc == ka && lkd == kb) ? 1 : 0;
+    const int given = __builtin_amdgcn_update_dpp(0, take, 0x101, 0xf, 0xf, false);  // row_shl:1: my right neighbour takes c, d
+    auto split = [&](float v, int &hi_i, int &lo_i) {
+      const float hi = rintf(v * s1);                  // exact product (power of two), |hi| <= 2^18
+      const float res = fmaf(-hi, inv_s1, v);          // exact residual, |res| <= 0.5 / S1
+      hi_i = (int)hi;
+      lo_i = (int)rintf(res * s1 * s2);
+    };
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      int ha, la, hb, lb, hc, lc, hd, ld;
+      split(wa * g[c], ha, la);
+      split(wb * g[c], hb, lb);
+      split(wc * g[c], hc, lc);
+      split(wd * g[c], hd, ld);
+      const int nhc = __builtin_amdgcn_update_dpp(0, hc, 0x111, 0xf, 0xf, false), nlc = __builtin_amdgcn_update_dpp(0, lc, 0x111, 0xf, 0xf, false);
+      const int nhd = __builtin_amdgcn_update_dpp(0, hd, 0x111, 0xf, 0xf, false), nld = __builtin_amdgcn_update_dpp(0, ld, 0x111, 0xf, 0xf, false);
+      if (take) { ha += nhc; la += nlc; hb += nhd; lb += nld; }
+      if (live) {
+        atomicAdd(win + ka + c, ha);
+        atomicAdd(win + kCells + ka + c, la);
+        atomicAdd(win + kb + c, hb);
+        atomicAdd(win + kCells + kb + c, lb);
+        if (!given) {
+          atomicAdd(win + kc + c, hc);
+          atomicAdd(win + kCells + kc + c, lc);
+          atomicAdd(win + kd + c, hd);
+          atomicAdd(win + kCells + kd + c, ld);
+        }
+      }
+    }
+  }
+#else
   if (live) {
     int *a = win + ((ty0 - wy0) * ww + (tx0 - wx0)) * C, *b = win + ((ty1 - wy0) * ww + (tx0 - wx0)) * C;
     int *c_ = win + ((ty0 - wy0) * ww + (tx1 - wx0)) * C, *d = win + ((ty1 - wy0) * ww + (tx1 - wx0)) * C;
@@ -1149,6 +1215,9 @@ __global__ __launch_bounds__(kSX * TY) void image_warp_bwd_im_tiled_kernel(const
       atomicAdd(cell, (int)hi);
       atomicAdd(cell + kCells, (int)rintf(res * s1 * s2));
     };
+#ifdef UNFLOW_TUNE_IM_NOSCATTER        // timing only: what the LDS atomics cost (one tap of twelve stays)
+    if (wa == 123.f)
+#endif
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       add(a + c, wa * g[c]);
@@ -1157,6 +1226,7 @@ __global__ __launch_bounds__(kSX * TY) void image_warp_bwd_im_tiled_kernel(const
       add(d + c, wd * g[c]);
     }
   }
+#endif
   __syncthreads();
   const int rowf = ww * C;                             // one window row = rowf contiguous floats in d_im
   const float inv_s12 = inv_s1 * (1.f / 524288.f);
@@ -1164,7 +1234,11 @@ __global__ __launch_bounds__(kSX * TY) void image_warp_bwd_im_tiled_kernel(const
     float *drow = base + ((long long)(wy0 + ly) * W + wx0) * C;
     for (int i = threadIdx.x & 63; i < rowf; i += 64) {
       const int hi = win[ly * rowf + i], lo = win[kCells + ly * rowf + i];
+#ifdef UNFLOW_TUNE_IM_NOFLUSH          // timing only: what the global atomics of the flush cost
+      if ((hi | lo) == 0x7fffffff) unsafeAtomicAdd(drow + i, fmaf((float)lo, inv_s12, (float)hi * inv_s1));
+#else
       if ((hi | lo) != 0) unsafeAtomicAdd(drow + i, fmaf((float)lo, inv_s12, (float)hi * inv_s1));
+#endif
     }
   }
 }
@@ -1191,6 +1265,21 @@ const char *tune_flags_warp() {
 #endif
 #ifdef UNFLOW_TUNE_FW_STAMPS
          " UNFLOW_TUNE_FW_STAMPS"
+#endif
+#ifdef UNFLOW_TUNE_IM3
+         " UNFLOW_TUNE_IM3"
+#endif
+#ifdef UNFLOW_TUNE_IM2
+         " UNFLOW_TUNE_IM2"
+#endif
+#ifdef UNFLOW_TUNE_IM_NOFLUSH
+         " UNFLOW_TUNE_IM_NOFLUSH"
+#endif
+#ifdef UNFLOW_TUNE_IM_MERGE
+         " UNFLOW_TUNE_IM_MERGE"
+#endif
+#ifdef UNFLOW_TUNE_IM_NOSCATTER
+         " UNFLOW_TUNE_IM_NOSCATTER"
 #endif
       ;
 }
@@ -1308,12 +1397,12 @@ extern "C" int unflow_image_warp_bwd(const float *grad, const float *im, const f
   }
   if (tiled_im) {
     // image gradient through the LDS-privatised scatter; the flow gradient (if wanted) separately
-    const dim3 tg((W + kSX - 1) / kSX, (H + kSY - 1) / kSY, B), tg8((W + kSX - 1) / kSX, (H + 7) / 8, B);
+    const dim3 tg((W + kIm2Cols - 1) / kIm2Cols, (H + kIm2Rows - 1) / kIm2Rows, B), tg3((W + kIm3Cols - 1) / kIm3Cols, (H + kIm3Rows - 1) / kIm3Rows, B);
     const float2 *fl = reinterpret_cast<const float2 *>(flow);
     if (zero_in_flow_kernel) FAST_LAUNCH(warp_bwd_flow_fast_kernel, true, grad, im, fl, reinterpret_cast<float2 *>(d_flow), d_im);
-    if (C == 1) hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<1, kSY>), tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
-    else if (C == 2) hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<2, kSY>), tg, dim3(kSplatThreads), 0, s, grad, fl, d_im, H, W);
-    else hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<3, 8>), tg8, dim3(kSX * 8), 0, s, grad, fl, d_im, H, W);
+    if (C == 1) hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<1, kIm2Cols, kIm2Rows, kIm2Win>), tg, dim3(kIm2Cols * kIm2Rows), 0, s, grad, fl, d_im, H, W);
+    else if (C == 2) hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<2, kIm2Cols, kIm2Rows, kIm2Win>), tg, dim3(kIm2Cols * kIm2Rows), 0, s, grad, fl, d_im, H, W);
+    else hipLaunchKernelGGL((image_warp_bwd_im_tiled_kernel<3, kIm3Cols, kIm3Rows, kIm3Win>), tg3, dim3(kIm3Cols * kIm3Rows), 0, s, grad, fl, d_im, H, W);
     if (d_flow && !zero_in_flow_kernel) { IW_BWD_C(false, true) }
   } else if (d_im && d_flow) { IW_BWD_C(true, true) }
   else if (d_im) { IW_BWD_C(true, false) }

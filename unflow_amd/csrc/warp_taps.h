@@ -41,21 +41,34 @@ struct ClampTaps {
   float xw, yw;
 };
 
-__device__ inline ClampTaps clamp_taps(int pos_x, int pos_y, float2 f, int H, int W) {
-  ClampTaps t;
+// The clamped tap coordinates themselves (a scatter kernel wants (x, y), not the flat index).
+struct ClampCoords {
+  int x0, y0, x1, y1;
+  float xw, yw;
+};
+
+__device__ inline ClampCoords clamp_tap_coords(int pos_x, int pos_y, float2 f, int H, int W) {
+  ClampCoords t;
   const float flx = floorf(f.x), fly = floorf(f.y);
   t.xw = f.x - flx;
   t.yw = f.y - fly;
-  int x0 = pos_x + (int)flx, y0 = pos_y + (int)fly;
-  int x1 = x0 + 1, y1 = y0 + 1;
-  x0 = min(max(x0, 0), W - 1);
-  x1 = min(max(x1, 0), W - 1);
-  y0 = min(max(y0, 0), H - 1);
-  y1 = min(max(y1, 0), H - 1);
-  t.ia = (long long)y0 * W + x0;
-  t.ib = (long long)y1 * W + x0;
-  t.ic = (long long)y0 * W + x1;
-  t.id = (long long)y1 * W + x1;
+  const int x0 = pos_x + (int)flx, y0 = pos_y + (int)fly;
+  t.x0 = min(max(x0, 0), W - 1);
+  t.x1 = min(max(x0 + 1, 0), W - 1);
+  t.y0 = min(max(y0, 0), H - 1);
+  t.y1 = min(max(y0 + 1, 0), H - 1);
+  return t;
+}
+
+__device__ inline ClampTaps clamp_taps(int pos_x, int pos_y, float2 f, int H, int W) {
+  const ClampCoords c = clamp_tap_coords(pos_x, pos_y, f, H, W);
+  ClampTaps t;
+  t.xw = c.xw;
+  t.yw = c.yw;
+  t.ia = (long long)c.y0 * W + c.x0;
+  t.ib = (long long)c.y1 * W + c.x0;
+  t.ic = (long long)c.y0 * W + c.x1;
+  t.id = (long long)c.y1 * W + c.x1;
   return t;
 }
 
