@@ -447,6 +447,37 @@ def test_warps_vs_oracle(oracle_mod, dev, B, H, W, C):
     close(d_flow, w_flow, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize("B,H,W,C,shift", [(2, 37, 53, 3, (-9.5, 4.25)), (1, 50, 75, 2, (20.0, -13.0)), (2, 33, 40, 1, (0.0, 0.0)),
+                                           (1, 48, 96, 3, (-60.0, 30.0))])
+def test_image_warp_image_gradient_coherent_flow(oracle_mod, dev, B, H, W, C, shift):
+    """The LDS-window path of the image gradient (csrc/warp.hip image_warp_bwd_im_tiled_kernel: 32 x 16 pixel tiles,
+    fixed-point window, a pixel's right-hand taps merged into its right neighbour's through DPP) on affine flows --
+    stretched, compressed and sheared, so that floor(flow) changes inside the 16-lane rows, that neighbouring lanes
+    share cells, and that whole rows and columns of taps are clamped at the image border (a translation that pushes
+    part of the image outside).  Ragged extents: lanes beyond the image take no part in the merge."""
+    from unflow_amd.image_warp import image_warp_grad
+    rng = np.random.default_rng(H * 100 + W)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+    flow = np.empty((B, H, W, 2), np.float32)
+    for b in range(B):
+        ax, ay = (0.23, -0.31) if b == 0 else (-0.4, 0.12)          # px / px: stretch in one item, compression in the other
+        flow[b, ..., 0] = shift[0] + ax * (xx - W / 2) + 0.11 * (yy - H / 2)
+        flow[b, ..., 1] = shift[1] + ay * (yy - H / 2) - 0.07 * (xx - W / 2)
+    flow += rng.uniform(-0.01, 0.01, flow.shape).astype(np.float32)
+    im = rng.uniform(size=(B, H, W, C)).astype(np.float32)
+    grad = rng.standard_normal(im.shape).astype(np.float32)
+    grad[0, 3:5, 7:20] = 0.0
+    d_im, d_flow = image_warp_grad(T(grad, dev), T(im, dev), T(flow, dev))
+    w_im, w_flow = oracle_mod.image_warp_grad(grad, im, flow)
+    close(d_im, w_im, 1e-5, 1e-5 * float(np.abs(w_im).max()))
+    close(d_flow, w_flow, 1e-5, 1e-5 * float(np.abs(w_flow).max()))
+    # the image gradient alone takes the memset + scatter route instead of the zeroing flow kernel
+    only_im, _ = image_warp_grad(T(grad, dev), T(im, dev), T(flow, dev), True, False)
+    close(only_im, w_im, 1e-5, 1e-5 * float(np.abs(w_im).max()))
+    # total mass: every tap weight quadruple sums to one, so the gradient's sum is conserved per channel
+    np.testing.assert_allclose(only_im.cpu().numpy().sum(axis=(0, 1, 2)), grad.sum(axis=(0, 1, 2)), rtol=1e-4, atol=1e-3)
+
+
 def test_image_warp_autograd(oracle_mod, dev):
     from unflow_amd.image_warp import image_warp
     rng = np.random.default_rng(11)
