@@ -782,6 +782,92 @@ def test_pyramid_loss_kitti_mix_gradient_vs_oracle(oracle_mod, dev, full_res):
             close(t.grad, w, 1e-5, 1e-5 * np.abs(w).max())
 
 
+@pytest.mark.parametrize("mask_occlusion,with_border,terms", [
+    ("fb", True, None), ("disocc", True, None), ("", False, None),
+    ("fb", True, ("ternary", "smooth_2nd", "occ")), ("fb", False, ("ternary",)), ("", True, ("sym", "photo", "fb"))])
+def test_compute_losses_stacked_equals_the_two_directions(oracle_mod, dev, mask_occlusion, with_border, terms):
+    """losses.compute_losses_stacked (both directions of losses.py:16-87 as one batch of 2B: [im1; im2], [im2; im1],
+    [flow_fw; flow_bw]) against compute_losses (one pass per direction) and against the oracle: every term, and the
+    gradient of a weighted sum of all of them to both flows."""
+    from unflow_amd import losses
+    rng = np.random.default_rng(91)
+    B, H, W = 3, 40, 72
+    im1, im2, _ = _pair(rng, B, H, W)
+    ffw = (rng.standard_normal((B, H, W, 2)) * 1.5 + rng.uniform(-4, 4, (B, 1, 1, 2))).astype(np.float32)
+    fbw = (-ffw + rng.standard_normal(ffw.shape) * 0.4).astype(np.float32)
+    border = oracle_mod.create_border_mask((B, H, W)) if with_border else None
+    names = terms or ("occ", "sym", "fb", "grad", "ternary", "photo", "smooth_1st", "smooth_2nd")
+    wts = {k: 0.3 + 0.2 * i for i, k in enumerate(names)}
+
+    def run(stacked):
+        a, b = T(ffw, dev).requires_grad_(True), T(fbw, dev).requires_grad_(True)
+        i1, i2 = T(im1, dev), T(im2, dev)
+        m = T(border, dev) if with_border else None
+        if stacked:
+            parts = losses.compute_losses_stacked(torch.cat((i1, i2)), torch.cat((i2, i1)), torch.cat((a, b)),
+                                                  border_mask=torch.cat((m, m)) if with_border else None,
+                                                  mask_occlusion=mask_occlusion, data_max_distance=2, terms=terms)
+            assert all(len(v) == 1 for v in parts.values())
+            vals = {k: v[0] for k, v in parts.items()}
+        else:
+            vals = losses.compute_losses(i1, i2, a, b, border_mask=m, mask_occlusion=mask_occlusion,
+                                         data_max_distance=2, terms=terms)
+        assert set(vals) == set(names)
+        sum(wts[k] * vals[k] for k in names).backward()
+        return {k: float(v.detach()) for k, v in vals.items()}, a.grad, b.grad
+
+    v2, ga2, gb2 = run(False)
+    v1, ga1, gb1 = run(True)
+    want, _ = oracle_mod.compute_losses(im1, im2, ffw, fbw, border, mask_occlusion, 2)
+    for k in names:
+        np.testing.assert_allclose(v1[k], v2[k], rtol=2e-6, err_msg=k)
+        np.testing.assert_allclose(v1[k], want[k], rtol=1e-5, err_msg=k)
+    for g1, g2 in ((ga1, ga2), (gb1, gb2)):
+        if g2 is None:
+            assert g1 is None or float(g1.abs().max()) == 0.0
+            continue
+        scale = float(g2.abs().max())
+        assert float((g1 - g2).abs().max()) <= 2e-6 * scale
+
+
+def test_pyramid_loss_stacked_levels_equal_the_unstacked(dev):
+    """unsupervised.pyramid_loss evaluates the levels below STACK_BELOW_PIXELS with both directions as one batch:
+    same scalar, same per-term sums, same gradients at every level as one pass per direction; and a pyramid whose
+    finest levels stay unstacked while the coarse ones stack (full_res with a threshold in between)."""
+    from unflow_amd import unsupervised
+    rng = np.random.default_rng(34)
+    B, H, W = 2, 128, 192
+    im1, im2, _ = _pair(rng, B, H, W)
+    border = np.ones((B, H, W, 1), np.float32)
+    border[:, :12] = 0
+    border[:, :, -20:] = 0
+    params = dict(full_res=True, pyramid_loss=True, mask_occlusion="fb", border_mask=True,
+                  ternary_weight=1.0, smooth_2nd_weight=3.0, fb_weight=0.2, occ_weight=12.4, grad_weight=0.5)
+    fws = [(rng.standard_normal((B, H >> i, W >> i, 2)) * 0.3).astype(np.float32) for i in range(7)]
+    bws = [(-f + rng.standard_normal(f.shape) * 0.05).astype(np.float32) for f in fws]
+
+    def run(stack, below):
+        old = unsupervised.STACK_DIRECTIONS, unsupervised.STACK_BELOW_PIXELS
+        unsupervised.STACK_DIRECTIONS, unsupervised.STACK_BELOW_PIXELS = stack, below
+        try:
+            tf_ = [T(f, dev).requires_grad_(True) for f in fws]
+            tb_ = [T(f, dev).requires_grad_(True) for f in bws]
+            got, terms = unsupervised.pyramid_loss(T(im1, dev), T(im2, dev), T(border, dev), tf_, tb_, params)
+            got.backward()
+            return float(got.detach()), {k: float(v) for k, v in terms.items()}, [t.grad for t in tf_ + tb_]
+        finally:
+            unsupervised.STACK_DIRECTIONS, unsupervised.STACK_BELOW_PIXELS = old
+
+    base = run(False, 0)
+    for below in (1 << 30, B * (H // 4) * (W // 4)):      # every level stacked; the two finest unstacked
+        got = run(True, below)
+        np.testing.assert_allclose(got[0], base[0], rtol=2e-6)
+        for k in base[1]:
+            np.testing.assert_allclose(got[1][k], base[1][k], rtol=2e-6, atol=1e-12, err_msg=k)
+        for g, w in zip(got[2], base[2]):
+            assert float((g - w).abs().max()) <= 2e-6 * float(w.abs().max())
+
+
 @pytest.mark.parametrize("full_res,pyramid", [(False, True), (True, True), (False, False)])
 def test_pyramid_loss_vs_oracle(oracle_mod, dev, full_res, pyramid):
     """core/unsupervised.py:83-145: layer weights, patch distances, flow scaling and the

@@ -577,88 +577,109 @@ def compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occl
     driver folds all of them into its weighted sum with ONE fused op instead of an add and a scale
     per term and level.  Returns (parts, aux)."""
     assert mask_occlusion in ['fb', 'disocc', '']
-    losses = {}
     B, H, W, _ = im1.shape
-    nb = norm_batch or B
-    npx = nb * H * W
-
-    want = (lambda k: True) if terms is None else (lambda k: k in terms)
+    npx = (norm_batch or B) * H * W
     # one alias of each flow per consumer (image warp, the two smoothness terms, flow and image of the flow warps,
     # the flow difference): their gradients are summed in one launch instead of five chained adds
     fw, bw = _fan_out(flow_fw, 6), _fan_out(flow_bw, 6)
-    im2_warped = im1_warped = None
-    # the warped images as graph nodes, unless the census term is their only consumer: then
+    # losses.py:16-87 writes every step once per direction; the two directions only meet in the other flow's role
+    # as the warped "image" of the forward-backward check (alias 4) and in the splat density of the other flow
+    l_fw, a_fw = _direction_losses(im1, im2, fw, bw[4], flow_fw, flow_bw, border_mask, mask_occlusion,
+                                   data_max_distance, npx, terms, return_aux)
+    l_bw, a_bw = _direction_losses(im2, im1, bw, fw[4], flow_bw, flow_fw, border_mask, mask_occlusion,
+                                   data_max_distance, npx, terms, return_aux)
+    losses = {k: (l_fw[k], l_bw[k]) for k in l_fw}
+    aux = dict(im2_warped=a_fw['warped'], im1_warped=a_bw['warped'], mask_fw=a_fw['mask'], mask_bw=a_bw['mask'],
+               disocc_fw=a_bw['disocc_other'], disocc_bw=a_fw['disocc_other'], flow_bw_warped=a_fw['flow_other_warped'],
+               flow_fw_warped=a_bw['flow_other_warped'], fb_occ_fw=a_fw['fb_occ'], fb_occ_bw=a_bw['fb_occ'])
+    return losses, aux
+
+
+def compute_losses_stacked(ims, ims_other, flows, border_mask=None, mask_occlusion='', data_max_distance=1,
+                           norm_batch=0, terms=None):
+    """Both directions of ``compute_losses`` (losses.py:16-87) as ONE batch of 2B (extension).  The reference evaluates
+    every step of the loss twice, once per direction, with the roles of the images and flows exchanged; nothing couples
+    the items of a batch, so the backward direction is the forward direction of B more pairs:
+
+        ims = [im1; im2], ims_other = [im2; im1], flows = [flow_fw; flow_bw]   (``[a; b]`` = concatenated along the batch)
+
+    and the other direction's flow of item b is item (b + B) mod 2B of ``flows``.  Every entry of the result is the
+    1-tuple (forward + backward sum), half the launches of ``compute_losses_parts`` -- what a loss pyramid's coarse
+    levels, whose launches do not fill the chip, are bound by.  ``border_mask`` is [2B,H,W,1] (the mask twice);
+    ``norm_batch`` the number of PAIRS the means are taken over (default B = half the stacked batch)."""
+    assert mask_occlusion in ['fb', 'disocc', '']
+    B2, H, W, _ = ims.shape
+    if B2 % 2 or flows.shape[0] != B2 or ims_other.shape != ims.shape:
+        raise ValueError("compute_losses_stacked expects [2B,H,W,C] images and [2B,H,W,2] flows")
+    B = B2 // 2
+    npx = (norm_batch or B) * H * W
+    fa = _fan_out(flows, 6)
+    want_fb = terms is None or 'fb' in terms
+    # the other direction's flow: the halves exchanged.  With 'fb' it is the image of a differentiable warp (alias 4)
+    other_img = torch.roll(fa[4], B, 0) if want_fb else None
+    need_raw = (terms is None or 'sym' in terms) or mask_occlusion in ('disocc', 'fb')
+    other_raw = other_img.detach() if other_img is not None else (torch.roll(flows.detach(), B, 0) if need_raw else None)
+    losses, _ = _direction_losses(ims, ims_other, fa, other_img, flows, other_raw, border_mask, mask_occlusion,
+                                  data_max_distance, npx, terms, False)
+    return {k: (v,) for k, v in losses.items()}
+
+
+def _direction_losses(im_a, im_b, fa, other_img, flow, flow_other, border_mask, mask_occlusion, data_max_distance,
+                      npx, terms, return_aux):
+    """One direction of losses.py:16-87: ``im_b`` is warped towards ``im_a`` by ``flow``; ``fa`` = the six aliases of
+    ``flow`` (``_fan_out``), ``other_img`` the other direction's flow in its role as the warped image of the
+    forward-backward check, ``flow_other`` the other direction's flow itself (density, occlusion test: no gradient)."""
+    losses = {}
+    want = (lambda k: True) if terms is None else (lambda k: k in terms)
+    b_warped = None
+    # the warped image as a graph node, unless the census term is its only consumer: then
     # ternary_loss_warped warps inside and differentiates straight down to the flow
     if want('photo') or want('grad') or return_aux:
-        im2_warped = image_warp(im2, fw[0])
-        im1_warped = image_warp(im1, bw[0])
+        b_warped = image_warp(im_b, fa[0])
     # Intermediates are only produced when something asks for them (TF1 runs just the nodes a
-    # fetched tensor needs): the splat densities for 'sym' / 'disocc' / aux, the warped flows
+    # fetched tensor needs): the splat density for 'sym' / 'disocc' / aux, the warped flow
     # for 'fb' / aux -- otherwise the occlusion test warps the other flow on the fly.
-    dens_fw = dens_bw = disocc_fw = disocc_bw = None
+    dens_other = disocc_other = None
     if want('sym') or mask_occlusion == 'disocc' or return_aux:
-        dens_fw = forward_warp(flow_fw.detach())
-        dens_bw = forward_warp(flow_bw.detach())
+        dens_other = forward_warp(flow_other.detach())
     if mask_occlusion == 'disocc' or return_aux:
         # tf.cast(forward_warp(flow) < DISOCC_THRESH): no gradient through the comparison
-        disocc_fw = (dens_fw < DISOCC_THRESH).float()
-        disocc_bw = (dens_bw < DISOCC_THRESH).float()
+        disocc_other = (dens_other < DISOCC_THRESH).float()
 
     if border_mask is None:
-        mask_fw = create_outgoing_mask(flow_fw)
-        mask_bw = create_outgoing_mask(flow_bw)
-    elif mask_occlusion == 'fb':       # the occlusion kernels write border_mask * (1 - occ) into fresh buffers: no copies
-        mask_fw = torch.empty_like(border_mask)
-        mask_bw = torch.empty_like(border_mask)
+        mask = create_outgoing_mask(flow)
+    elif mask_occlusion == 'fb':       # the occlusion kernels write border_mask * (1 - occ) into a fresh buffer: no copy
+        mask = torch.empty_like(border_mask)
     else:
-        mask_fw = border_mask.clone()
-        mask_bw = border_mask.clone()
+        mask = border_mask.clone()
 
-    flow_bw_warped = flow_fw_warped = fb_occ_fw = fb_occ_bw = None
+    flow_other_warped = fb_occ = diff = None
     if want('fb') or return_aux:
-        flow_bw_warped = image_warp(bw[4], fw[3])
-        flow_fw_warped = image_warp(fw[4], bw[3])
+        flow_other_warped = image_warp(other_img, fa[3])
         fb = mask_occlusion == 'fb'
-        diff_fw, fb_occ_fw = fb_occlusion(flow_fw, flow_bw_warped, mask_fw if fb else None, mask_in=border_mask if fb else None)
-        diff_bw, fb_occ_bw = fb_occlusion(flow_bw, flow_fw_warped, mask_bw if fb else None, mask_in=border_mask if fb else None)
+        diff, fb_occ = fb_occlusion(flow, flow_other_warped, mask if fb else None, mask_in=border_mask if fb else None)
     elif mask_occlusion == 'fb':
-        src = border_mask if border_mask is not None else None
-        _, fb_occ_fw = fb_occlusion_warp(flow_fw, flow_bw, mask_fw, mask_in=src)
-        _, fb_occ_bw = fb_occlusion_warp(flow_bw, flow_fw, mask_bw, mask_in=src)
+        _, fb_occ = fb_occlusion_warp(flow, flow_other, mask, mask_in=border_mask)
     if mask_occlusion == 'disocc':
-        mask_fw = mask_fw * (1 - disocc_bw)
-        mask_bw = mask_bw * (1 - disocc_fw)
+        mask = mask * (1 - disocc_other)
 
     if want('sym'):
-        losses['sym'] = (sym_loss(mask_fw, dens_bw, norm_count=npx), sym_loss(mask_bw, dens_fw, norm_count=npx))
+        losses['sym'] = sym_loss(mask, dens_other, norm_count=npx)
     if want('occ'):      # charbonnier_loss(1 - mask), the complement taken inside the kernel
-        losses['occ'] = (occ_loss(mask_fw, norm_count=npx), occ_loss(mask_bw, norm_count=npx))
+        losses['occ'] = occ_loss(mask, norm_count=npx)
     if want('photo'):
-        losses['photo'] = (charbonnier_loss(im1 - im2_warped, mask_fw, beta=255, norm_count=npx * 3),
-                           charbonnier_loss(im2 - im1_warped, mask_bw, beta=255, norm_count=npx * 3))
+        losses['photo'] = charbonnier_loss(im_a - b_warped, mask, beta=255, norm_count=npx * 3)
     if want('grad'):
-        losses['grad'] = (gradient_loss(im1, im2_warped, mask_fw, norm_count=npx * 6),
-                          gradient_loss(im2, im1_warped, mask_bw, norm_count=npx * 6))
+        losses['grad'] = gradient_loss(im_a, b_warped, mask, norm_count=npx * 6)
     if want('smooth_1st'):
-        losses['smooth_1st'] = (smoothness_loss(fw[1], norm_count=npx * 2),
-                                smoothness_loss(bw[1], norm_count=npx * 2))
+        losses['smooth_1st'] = smoothness_loss(fa[1], norm_count=npx * 2)
     if want('smooth_2nd'):
-        losses['smooth_2nd'] = (second_order_loss(fw[2], norm_count=npx * 4),
-                                second_order_loss(bw[2], norm_count=npx * 4))
+        losses['smooth_2nd'] = second_order_loss(fa[2], norm_count=npx * 4)
     if want('fb'):       # flow + warped other flow: the sum the occlusion kernel already wrote (same rounding)
-        losses['fb'] = (charbonnier_loss(_FlowDiff.apply(fw[5], flow_bw_warped, diff_fw), mask_fw, norm_count=npx * 2),
-                        charbonnier_loss(_FlowDiff.apply(bw[5], flow_fw_warped, diff_bw), mask_bw, norm_count=npx * 2))
-    if want('ternary') and im2_warped is None:
-        losses['ternary'] = (ternary_loss_warped(im1, im2, fw[0], mask_fw, max_distance=data_max_distance,
-                                                 norm_count=npx),
-                             ternary_loss_warped(im2, im1, bw[0], mask_bw, max_distance=data_max_distance,
-                                                 norm_count=npx))
+        losses['fb'] = charbonnier_loss(_FlowDiff.apply(fa[5], flow_other_warped, diff), mask, norm_count=npx * 2)
+    if want('ternary') and b_warped is None:
+        losses['ternary'] = ternary_loss_warped(im_a, im_b, fa[0], mask, max_distance=data_max_distance, norm_count=npx)
     elif want('ternary'):
-        losses['ternary'] = (ternary_loss(im1, im2_warped, mask_fw, max_distance=data_max_distance,
-                                          norm_count=npx),
-                             ternary_loss(im2, im1_warped, mask_bw, max_distance=data_max_distance,
-                                          norm_count=npx))
-    aux = dict(im2_warped=im2_warped, im1_warped=im1_warped, mask_fw=mask_fw, mask_bw=mask_bw,
-               disocc_fw=disocc_fw, disocc_bw=disocc_bw, flow_bw_warped=flow_bw_warped,
-               flow_fw_warped=flow_fw_warped, fb_occ_fw=fb_occ_fw, fb_occ_bw=fb_occ_bw)
+        losses['ternary'] = ternary_loss(im_a, b_warped, mask, max_distance=data_max_distance, norm_count=npx)
+    aux = dict(warped=b_warped, mask=mask, disocc_other=disocc_other, flow_other_warped=flow_other_warped, fb_occ=fb_occ)
     return losses, aux

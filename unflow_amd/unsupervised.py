@@ -10,13 +10,18 @@ passes the pyramid in and adds its own regularisation loss.
 import torch
 
 from . import _lib
-from .losses import DeferredReductions, compute_losses_parts
+from .losses import DeferredReductions, compute_losses_parts, compute_losses_stacked
 from .util import downsample
 
 # unsupervised.py:10
 LOSSES = ['occ', 'sym', 'fb', 'grad', 'ternary', 'photo', 'smooth_1st', 'smooth_2nd']
 assert len(LOSSES) <= _lib.PLAN_TERMS      # one per-term sum of unflow_reduce_plan_run each
 FLOW_SCALE = 5.0  # core/flownet.py:11
+# a pyramid level with at most this many pixels per direction (B * h * w) runs its two directions as one batch
+# (32 x 96 x 320, the finest default level of a KITTI batch, does; the two full_res levels in front of it do not:
+# stacking copies the images, which only pays where a launch is bound by its latency)
+STACK_DIRECTIONS = True
+STACK_BELOW_PIXELS = 1 << 21
 
 
 # per pyramid level, finest first: (layer weight, census patch distance)
@@ -65,15 +70,29 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     # joined to the caller's stream -- the captured graph then has five parallel branches.  Eager 3.5 -> 6-9 ms (the
     # host pays for the event traffic), graph replay 1.197 -> 1.30 ms, and the replayed gradients differed from the
     # eager ones by 2.6e-3 of their scale: the levels stay on one stream.)
+    # Levels whose launches do not fill the chip evaluate both directions as ONE batch of 2B (losses.compute_losses_stacked:
+    # the backward direction is the forward direction of B more pairs), half the launches; from the first such level on
+    # the image chain is the stacked one ([im1; im2], [im2; im1], the mask twice).
     scalars, coeffs, owners = [], [], []
+    stacked = False
     with DeferredReductions(im1_norm.device) as deferred:
         for i in range(n_levels):
             layer_weight, patch_distance = levels[i]
+            if not stacked and STACK_DIRECTIONS and images[0].shape[0] * images[0].shape[1] * images[0].shape[2] <= STACK_BELOW_PIXELS:
+                im1_s, im2_s, mask_s = images
+                images = (torch.cat((im1_s, im2_s)), torch.cat((im2_s, im1_s)), torch.cat((mask_s, mask_s)))
+                stacked = True
             im1_s, im2_s, mask_s = images
-            level = compute_losses_parts(im1_s, im2_s, scaled_fw[i], scaled_bw[i],
-                                         border_mask=mask_s if params.get('border_mask') else None,
-                                         mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
-                                         norm_batch=norm_batch, terms=tuple(weights))[0]
+            if stacked:
+                level = compute_losses_stacked(im1_s, im2_s, torch.cat((scaled_fw[i], scaled_bw[i])),
+                                               border_mask=mask_s if params.get('border_mask') else None,
+                                               mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
+                                               norm_batch=norm_batch, terms=tuple(weights))
+            else:
+                level = compute_losses_parts(im1_s, im2_s, scaled_fw[i], scaled_bw[i],
+                                             border_mask=mask_s if params.get('border_mask') else None,
+                                             mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
+                                             norm_batch=norm_batch, terms=tuple(weights))[0]
             for name, weight in weights.items():                                   # :134-139
                 for part in level[name]:
                     scalars.append(part)
