@@ -596,7 +596,7 @@ def compute_losses_parts(im1, im2, flow_fw, flow_bw, border_mask=None, mask_occl
 
 
 def compute_losses_stacked(ims, ims_other, flows, border_mask=None, mask_occlusion='', data_max_distance=1,
-                           norm_batch=0, terms=None):
+                           norm_batch=0, terms=None, flows_other=None):
     """Both directions of ``compute_losses`` (losses.py:16-87) as ONE batch of 2B (extension).  The reference evaluates
     every step of the loss twice, once per direction, with the roles of the images and flows exchanged; nothing couples
     the items of a batch, so the backward direction is the forward direction of B more pairs:
@@ -606,7 +606,9 @@ def compute_losses_stacked(ims, ims_other, flows, border_mask=None, mask_occlusi
     and the other direction's flow of item b is item (b + B) mod 2B of ``flows``.  Every entry of the result is the
     1-tuple (forward + backward sum), half the launches of ``compute_losses_parts`` -- what a loss pyramid's coarse
     levels, whose launches do not fill the chip, are bound by.  ``border_mask`` is [2B,H,W,1] (the mask twice);
-    ``norm_batch`` the number of PAIRS the means are taken over (default B = half the stacked batch)."""
+    ``norm_batch`` the number of PAIRS the means are taken over (default B = half the stacked batch).  ``flows_other``:
+    ``[flow_bw; flow_fw]`` if the caller has it (the pyramid driver makes both orders in one launch); else it is
+    rolled from ``flows`` here."""
     assert mask_occlusion in ['fb', 'disocc', '']
     B2, H, W, _ = ims.shape
     if B2 % 2 or flows.shape[0] != B2 or ims_other.shape != ims.shape:
@@ -616,9 +618,14 @@ def compute_losses_stacked(ims, ims_other, flows, border_mask=None, mask_occlusi
     fa = _fan_out(flows, 6)
     want_fb = terms is None or 'fb' in terms
     # the other direction's flow: the halves exchanged.  With 'fb' it is the image of a differentiable warp (alias 4)
-    other_img = torch.roll(fa[4], B, 0) if want_fb else None
-    need_raw = (terms is None or 'sym' in terms) or mask_occlusion in ('disocc', 'fb')
-    other_raw = other_img.detach() if other_img is not None else (torch.roll(flows.detach(), B, 0) if need_raw else None)
+    if flows_other is not None:
+        if flows_other.shape != flows.shape:
+            raise ValueError("flows_other must have the shape of flows")
+        other_img, other_raw = (flows_other if want_fb else None), flows_other.detach()
+    else:
+        other_img = torch.roll(fa[4], B, 0) if want_fb else None
+        need_raw = (terms is None or 'sym' in terms) or mask_occlusion in ('disocc', 'fb')
+        other_raw = other_img.detach() if other_img is not None else (torch.roll(flows.detach(), B, 0) if need_raw else None)
     losses, _ = _direction_losses(ims, ims_other, fa, other_img, flows, other_raw, border_mask, mask_occlusion,
                                   data_max_distance, npx, terms, False)
     return {k: (v,) for k, v in losses.items()}

@@ -54,10 +54,25 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     # TF1 only runs what the fetched scalar needs: terms without a weight are never evaluated
     weights = {name: params[name + '_weight'] for name in LOSSES if params.get(name + '_weight')}
 
-    # flow scaling of every level (:118) as ONE multi-tensor launch (and one for its gradient)
+    # flow scaling of every level (:118) as ONE multi-tensor launch (and one for its gradient).  Levels whose launches
+    # do not fill the chip evaluate both directions as ONE batch of 2B (losses.compute_losses_stacked: the backward
+    # direction is the forward direction of B more pairs), half the launches; the pixel count falls from level to level,
+    # so these are the levels from `stack_from` on, and their scaled flows come out stacked in both orders
+    # ([fw; bw] and, for the other direction's role, [bw; fw]) from the same pair of launches.
     scales = [top_scale / (2 ** i) for i in range(n_levels)]
-    scaled = _scale_all(scales + scales, list(flows_fw[:n_levels]) + list(flows_bw[:n_levels]))
-    scaled_fw, scaled_bw = scaled[:n_levels], scaled[n_levels:]
+    stack_from = n_levels
+    if STACK_DIRECTIONS:
+        for i in range(n_levels):
+            if flows_fw[i].shape[0] * flows_fw[i].shape[1] * flows_fw[i].shape[2] <= STACK_BELOW_PIXELS:
+                stack_from = i
+                break
+    scaled = _scale_all(scales[:stack_from] * 2, list(flows_fw[:stack_from]) + list(flows_bw[:stack_from])) if stack_from else []
+    scaled_fw, scaled_bw = scaled[:stack_from], scaled[stack_from:]
+    n_st = n_levels - stack_from
+    if n_st:
+        st = _ScaleStack.apply([float(x) for x in scales[stack_from:]],
+                               *(list(flows_fw[stack_from:n_levels]) + list(flows_bw[stack_from:n_levels])))
+        stacked_flows, stacked_other = st[:n_st], st[n_st:]
 
     # The reference adds up  layer_weight * sum_k weight_k * loss_k  term by term (:134-141).  On the
     # GPU every one of those scalar multiplies and adds is a kernel launch (about 200 of the ~400
@@ -70,21 +85,18 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     # joined to the caller's stream -- the captured graph then has five parallel branches.  Eager 3.5 -> 6-9 ms (the
     # host pays for the event traffic), graph replay 1.197 -> 1.30 ms, and the replayed gradients differed from the
     # eager ones by 2.6e-3 of their scale: the levels stay on one stream.)
-    # Levels whose launches do not fill the chip evaluate both directions as ONE batch of 2B (losses.compute_losses_stacked:
-    # the backward direction is the forward direction of B more pairs), half the launches; from the first such level on
-    # the image chain is the stacked one ([im1; im2], [im2; im1], the mask twice).
+    # From level `stack_from` on the image chain is the stacked one ([im1; im2], [im2; im1], the mask twice).
     scalars, coeffs, owners = [], [], []
-    stacked = False
     with DeferredReductions(im1_norm.device) as deferred:
         for i in range(n_levels):
             layer_weight, patch_distance = levels[i]
-            if not stacked and STACK_DIRECTIONS and images[0].shape[0] * images[0].shape[1] * images[0].shape[2] <= STACK_BELOW_PIXELS:
+            if i == stack_from:
                 im1_s, im2_s, mask_s = images
                 images = (torch.cat((im1_s, im2_s)), torch.cat((im2_s, im1_s)), torch.cat((mask_s, mask_s)))
-                stacked = True
             im1_s, im2_s, mask_s = images
-            if stacked:
-                level = compute_losses_stacked(im1_s, im2_s, torch.cat((scaled_fw[i], scaled_bw[i])),
+            if i >= stack_from:
+                level = compute_losses_stacked(im1_s, im2_s, stacked_flows[i - stack_from],
+                                               flows_other=stacked_other[i - stack_from],
                                                border_mask=mask_s if params.get('border_mask') else None,
                                                mask_occlusion=mask_occlusion, data_max_distance=patch_distance,
                                                norm_batch=norm_batch, terms=tuple(weights))
@@ -164,6 +176,51 @@ class _ScaleAll(torch.autograd.Function):
         if live:
             for (i, _), g in zip(live, torch._foreach_mul([g.contiguous() for _, g in live], [ctx.scales[i] for i, _ in live])):
                 out[i] = g
+        return (None,) + tuple(out)
+
+
+class _ScaleStack(torch.autograd.Function):
+    """For n levels: (fw_i, bw_i) -> F_i = scale_i * [fw_i; bw_i] and G_i = scale_i * [bw_i; fw_i] ([a; b]: along the batch).
+    Two multi-tensor launches for all levels (scale; copy into the halves), two for the gradient (add the two orders'
+    halves; scale) -- against a concatenation, a roll and the roll's gradient per level."""
+
+    @staticmethod
+    def forward(ctx, scales, *tensors):
+        n = len(scales)
+        ctx.scales = scales
+        ctx.set_materialize_grads(False)
+        scaled = torch._foreach_mul(list(tensors), scales + scales)
+        fw, bw = scaled[:n], scaled[n:]
+        B = tensors[0].shape[0]
+        ctx.B = B
+        F = [t.new_empty((2 * B,) + tuple(t.shape[1:])) for t in fw]
+        G = [t.new_empty((2 * B,) + tuple(t.shape[1:])) for t in fw]
+        torch._foreach_copy_([f[:B] for f in F] + [f[B:] for f in F] + [g[B:] for g in G] + [g[:B] for g in G],
+                             list(fw) + list(bw) + list(fw) + list(bw))
+        return tuple(F) + tuple(G)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n, B = len(ctx.scales), ctx.B
+        gF, gG = grads[:n], grads[n:]
+        out = [None] * (2 * n)
+        both = [i for i in range(n) if gF[i] is not None and gG[i] is not None]
+        one = [i for i in range(n) if (gF[i] is None) != (gG[i] is None)]
+        parts, where = [], []
+        if both:      # d fw = F's first half + G's second, d bw = F's second half + G's first
+            a = [gF[i][:B] for i in both] + [gF[i][B:] for i in both]
+            b = [gG[i][B:] for i in both] + [gG[i][:B] for i in both]
+            parts += list(torch._foreach_add(a, b))
+            where += both + [n + i for i in both]
+        for i in one:
+            if gF[i] is not None:
+                parts += [gF[i][:B], gF[i][B:]]
+            else:
+                parts += [gG[i][B:], gG[i][:B]]
+            where += [i, n + i]
+        if parts:
+            for k, g in zip(where, torch._foreach_mul(parts, [ctx.scales[k % n] for k in where])):
+                out[k] = g
         return (None,) + tuple(out)
 
 
