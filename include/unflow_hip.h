@@ -36,7 +36,7 @@ extern "C" {
 #define UNFLOW_ERR_INVALID_ARGUMENT 1 /* tf errors::InvalidArgument */
 #define UNFLOW_ERR_LAUNCH 2           /* hipGetLastError() after a launch */
 
-#define UNFLOW_ABI_VERSION 4
+#define UNFLOW_ABI_VERSION 5
 
 typedef void *unflow_stream_t; /* hipStream_t */
 
@@ -115,6 +115,13 @@ int unflow_forward_warp_bwd(const float *input_grad, const float *flows, float *
  * and width must be divisible by scale" (ops/downsample_op.cc:37-40). */
 int unflow_downsample_fwd(const float *images, float *output, int B, int H, int W, int C, int scale,
                           unflow_stream_t stream);
+/* The image chain of the loss pyramid (src/e2eflow/core/unsupervised.py:97-103,143-145: downsample by 4, then
+ * by 2 per level) in one launch, bit-identical to the chain of unflow_downsample_fwd calls.  im_a, im_b [B,H,W,C]
+ * (C = 1 or 3; im_b may be NULL); out_ab / out_ba: HOST arrays of `levels` (<= 5) device pointers, level l being
+ * [B or 2B, H/(4<<l), W/(4<<l), C].  With im_b the outputs are stacked along the batch: out_ab[l] = [a; b] and
+ * (if out_ba is given) out_ba[l] = [b; a].  H and W must be divisible by 4 << (levels - 1). */
+int unflow_downsample_pyramid(const float *im_a, const float *im_b, float *const *out_ab, float *const *out_ba,
+                              int levels, int B, int H, int W, int C, unflow_stream_t stream);
 
 /* ---------------------------------------------------------------- census loss
  * Replaces ternary_loss (src/e2eflow/core/losses.py:90-122), the soft

@@ -419,6 +419,38 @@ def test_correlation_errors(dev):
         ops.downsample(torch.zeros((1, 5, 4, 1), device=dev), 2)
 
 
+@pytest.mark.parametrize("B,H,W,C,levels", [(2, 128, 192, 3, 5), (3, 64, 64, 1, 5), (1, 96, 160, 3, 3), (2, 40, 72, 1, 2),
+                                            (1, 384, 1280, 3, 5), (2, 12, 20, 3, 1)])
+def test_downsample_pyramid_is_the_chain_bit_for_bit(dev, B, H, W, C, levels):
+    """ops.downsample_pyramid (one launch for the image chain of core/unsupervised.py:97-103,143-145) against the chain of
+    ops.downsample calls it replaces: every level bit-identical, for one tensor and for the stacked orders [a; b], [b; a];
+    extents that are not multiples of the kernel's 64 x 64 block; the chain's own error for indivisible extents."""
+    from unflow_amd import ops
+    g = torch.Generator(device=dev)
+    g.manual_seed(B * 100 + H)
+    a = torch.rand((B, H, W, C), device=dev, generator=g)
+    b = torch.rand((B, H, W, C), device=dev, generator=g)
+
+    def chain(x):
+        out = [ops.downsample(x, 4)]
+        for _ in range(levels - 1):
+            out.append(ops.downsample(out[-1], 2))
+        return out
+
+    ca, cb = chain(a), chain(b)
+    one = ops.downsample_pyramid(a, None, levels)
+    ab = ops.downsample_pyramid(a, b, levels)
+    ab2, ba2 = ops.downsample_pyramid(a, b, levels, both_orders=True)
+    for l in range(levels):
+        assert one[l].shape == ca[l].shape and torch.equal(one[l], ca[l]), l
+        assert torch.equal(ab[l], torch.cat((ca[l], cb[l]))), l
+        assert torch.equal(ab2[l], ab[l]) and torch.equal(ba2[l], torch.cat((cb[l], ca[l]))), l
+    with pytest.raises(ValueError, match="divisible by scale"):
+        ops.downsample_pyramid(torch.zeros((1, 8 << levels, (4 << levels) - 4, C), device=dev), None, levels + 1 if levels < 5 else 5)
+    with pytest.raises(ValueError, match="both_orders"):
+        ops.downsample_pyramid(a, None, levels, both_orders=True)
+
+
 def _pair(rng, B, H, W):
     from tests.golden.make_golden import smooth_field
     im1 = smooth_field(rng, (B, H, W, 3), 2.0)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # kernel with -D knobs); never a fallback -- a missing file raises like the default path does.
 LIB_PATH = os.environ.get("UNFLOW_HIP_LIB") or os.path.join(_HERE, "libunflow_hip.so")
 
-ABI_VERSION = 4      # UNFLOW_ABI_VERSION of include/unflow_hip.h
+ABI_VERSION = 5      # UNFLOW_ABI_VERSION of include/unflow_hip.h
 UNFLOW_OK = 0
 UNFLOW_ERR_INVALID_ARGUMENT = 1
 UNFLOW_ERR_LAUNCH = 2
@@ -39,6 +39,7 @@ SIGNATURES = {
     "unflow_forward_warp_fwd": (_I, [_P, _P, _I, _I, _I, _P]),
     "unflow_forward_warp_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "unflow_downsample_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "unflow_downsample_pyramid": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "unflow_reduce_workspace_floats": (ctypes.c_size_t, [_I, _I, _I]),
     "unflow_reduce_plan_begin": (_I, [_P]),
     "unflow_reduce_plan_end": (_I, []),

@@ -1046,6 +1046,85 @@ __global__ __launch_bounds__(kBlock) void downsample_px_kernel(const float *__re
   for (int c = 0; c < C; ++c) out[c] = sum[c] / (float)(SCALE * SCALE);
 }
 
+// The image chain of the loss pyramid (core/unsupervised.py:97-103,143-145: downsample by 4, then by 2 per level) in ONE
+// launch: a workgroup reads a 64 x 64 block of one image (coalesced 16-byte loads, 16 rows at a time through LDS) and
+// writes its 16 x 16 pixels of level 0, 8 x 8 of level 1, ... 1 x 1 of level 4.  Every output is computed exactly as the
+// chain of downsample_px_kernel launches computes it -- the taps of a window added one after the other in row-major
+// order, then the division -- so the results are the chain's bit for bit.  With two source tensors the outputs are
+// the stacked batches the pyramid driver wants: ab = [a; b] and (optionally) ba = [b; a] along the batch.
+constexpr int kPyrLevels = 5, kPyrBlock = 64, kPyrStrip = 16;
+struct PyrArgs {
+  const float *src[2];
+  float *ab[kPyrLevels], *ba[kPyrLevels];
+};
+template <int C>
+__global__ __launch_bounds__(256) void downsample_pyramid_kernel(PyrArgs a, int levels, int B, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float strip[kPyrStrip * kPyrBlock * C];
+  __shared__ float lv[16 * 16 * C + 8 * 8 * C + 4 * 4 * C + 2 * 2 * C];
+  const int which = blockIdx.z / B, b = blockIdx.z % B;
+  const float *src = a.src[which] + (long long)b * H * W * C;
+  const int x0 = blockIdx.x * kPyrBlock, y0 = blockIdx.y * kPyrBlock;
+  const int H0 = H / 4, W0 = W / 4;
+  const long long item_ab = (long long)which * B + b, item_ba = (long long)(1 - which) * B + b;
+  constexpr int kRowF4 = kPyrBlock * C / 4;                  // 16-byte pieces of a block row
+  const int row_floats = min(kPyrBlock, W - x0) * C;         // W % 4 == 0: whole pieces
+  for (int st = 0; st < kPyrBlock / kPyrStrip; ++st) {
+    __syncthreads();                                         // the previous strip has been consumed
+    for (int i = threadIdx.x; i < kPyrStrip * kRowF4; i += 256) {
+      const int r = i / kRowF4, q = i - r * kRowF4;
+      const int y = y0 + st * kPyrStrip + r;
+      typedef float f4_t __attribute__((ext_vector_type(4)));
+      f4_t v = {0.f, 0.f, 0.f, 0.f};
+      if (y < H && q * 4 < row_floats)
+        v = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(src + ((long long)y * W + x0) * C) + q);
+      reinterpret_cast<f4_t *>(strip)[i] = v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < 4 * 16 * C; o += 256) {    // 4 rows x 16 pixels x C of level 0
+      const int c = o % C, px = (o / C) % 16, py = o / (16 * C);
+      float sum = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) sum += strip[((py * 4 + dy) * kPyrBlock + px * 4 + dx) * C + c];
+      const float v = sum / 16.f;
+      const int ly = st * 4 + py;
+      lv[(ly * 16 + px) * C + c] = v;
+      const int gx = x0 / 4 + px, gy = y0 / 4 + ly;
+      if (gx < W0 && gy < H0) {
+        const long long at = ((long long)gy * W0 + gx) * C + c, per = (long long)H0 * W0 * C;
+        a.ab[0][item_ab * per + at] = v;
+        if (a.ba[0]) a.ba[0][item_ba * per + at] = v;
+      }
+    }
+  }
+  int in_off = 0, side = 16;
+  for (int l = 1; l < levels; ++l) {
+    __syncthreads();
+    const int half = side / 2, out_off = in_off + side * side * C;
+    const int Hl = H0 >> l, Wl = W0 >> l;
+    for (int o = threadIdx.x; o < half * half * C; o += 256) {
+      const int c = o % C, px = (o / C) % half, py = o / (half * C);
+      const float *p = lv + in_off + ((py * 2) * side + px * 2) * C + c;
+      float sum = 0.f;
+      sum += p[0];
+      sum += p[C];
+      sum += p[side * C];
+      sum += p[side * C + C];
+      const float v = sum / 4.f;
+      if (l < 4) lv[out_off + (py * half + px) * C + c] = v;
+      const int gx = (x0 >> (2 + l)) + px, gy = (y0 >> (2 + l)) + py;
+      if (gx < Wl && gy < Hl) {
+        const long long at = ((long long)gy * Wl + gx) * C + c, per = (long long)Hl * Wl * C;
+        a.ab[l][item_ab * per + at] = v;
+        if (a.ba[l]) a.ba[l][item_ba * per + at] = v;
+      }
+    }
+    in_off = out_off;
+    side = half;
+  }
+}
+
 // Image gradient of image_warp (the scatter-add TF derives from tf.gather), LDS-privatised.
 // One workgroup owns a tile of pixels (32 x 16); the cells its 2x2 taps touch form a bounding
 // box that -- for a coherent flow -- is little larger than the tile.  The taps are added
@@ -1533,4 +1612,34 @@ extern "C" int unflow_downsample_fwd(const float *images, float *output, int B, 
   hipLaunchKernelGGL(downsample_kernel, dim3(grid_for(total)), dim3(kBlock), 0, as_stream(stream), images,
                      output, H, W, C, oh, ow, scale, total);
   return launch_status("downsample");
+}
+
+extern "C" int unflow_downsample_pyramid(const float *im_a, const float *im_b, float *const *out_ab,
+                                         float *const *out_ba, int levels, int B, int H, int W, int C,
+                                         unflow_stream_t stream) {
+  if (int rc = check_dims("downsample_pyramid", B, H, W, C)) return rc;
+  if (levels < 1 || levels > kPyrLevels) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: 1 to 5 levels");
+  if (C != 1 && C != 3) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: 1 or 3 channels");
+  const int step = 4 << (levels - 1);
+  if (H % step != 0 || W % step != 0)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "Input height and width must be divisible by scale");   // the chain's own error
+  if (!im_a || !out_ab) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: null tensor");
+  if ((reinterpret_cast<uintptr_t>(im_a) & 15) || (im_b && (reinterpret_cast<uintptr_t>(im_b) & 15)))
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: images must be 16-byte aligned");
+  if (out_ba && !im_b) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: the second order needs two tensors");
+  const long long nimg = (long long)B * (im_b ? 2 : 1);
+  if (nimg == 0 || H == 0 || W == 0) return UNFLOW_OK;
+  if (nimg > 65535) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: at most 65535 images per launch");
+  PyrArgs a;
+  a.src[0] = im_a;
+  a.src[1] = im_b ? im_b : im_a;
+  for (int l = 0; l < kPyrLevels; ++l) {
+    a.ab[l] = l < levels ? out_ab[l] : nullptr;
+    a.ba[l] = (out_ba && l < levels) ? out_ba[l] : nullptr;
+    if (l < levels && !a.ab[l]) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: null output level");
+  }
+  const dim3 g((W + kPyrBlock - 1) / kPyrBlock, (H + kPyrBlock - 1) / kPyrBlock, (unsigned)nimg);
+  if (C == 1) hipLaunchKernelGGL(downsample_pyramid_kernel<1>, g, dim3(256), 0, as_stream(stream), a, levels, B, H, W);
+  else hipLaunchKernelGGL(downsample_pyramid_kernel<3>, g, dim3(256), 0, as_stream(stream), a, levels, B, H, W);
+  return launch_status("downsample_pyramid");
 }

@@ -193,6 +193,38 @@ def downsample(images, scale=2):
     return out
 
 
+def downsample_pyramid(im_a, im_b=None, levels=5, both_orders=False):
+    """The image chain of the loss pyramid (core/unsupervised.py:97-103,143-145) as ONE launch (extension):
+    ``downsample(x, 4)`` followed by ``levels - 1`` times ``downsample(., 2)``, every level bit-identical to the
+    chain of ``downsample`` calls.  With ``im_b`` the levels are the stacked batches ``[a; b]`` (and, with
+    ``both_orders``, also ``[b; a]``) along the batch.  Returns the list of levels (or the two lists).  One or
+    three channels, at most five levels, extents divisible by ``4 << (levels - 1)``; not differentiable."""
+    import ctypes
+    im_a = _dev(im_a.detach(), "im_a")
+    _require_rank4(im_a, "im_a")
+    if im_b is not None:
+        im_b = _dev(im_b.detach(), "im_b")
+        if im_b.shape != im_a.shape:
+            raise ValueError("downsample_pyramid: im_a %s and im_b %s must have the same shape" % (tuple(im_a.shape), tuple(im_b.shape)))
+    elif both_orders:
+        raise ValueError("downsample_pyramid: both_orders needs two tensors")
+    B, H, W, C = im_a.shape
+    if not 1 <= levels <= 5:
+        raise ValueError("downsample_pyramid: 1 to 5 levels")
+    step = 4 << (levels - 1)
+    if H % step != 0 or W % step != 0:
+        raise ValueError("Input height and width must be divisible by scale")
+    nb = B * (2 if im_b is not None else 1)
+    mk = lambda: [torch.empty((nb, H // (4 << l), W // (4 << l), C), device=im_a.device, dtype=torch.float32) for l in range(levels)]
+    ab = mk()
+    ba = mk() if both_orders else None
+    arr = lambda ts: (ctypes.c_void_p * levels)(*[t.data_ptr() for t in ts])
+    with _on(im_a.device):
+        _lib.check(_lib.load().unflow_downsample_pyramid(_ptr(im_a), _ptr(im_b), arr(ab), arr(ba) if ba else None,
+                                                         levels, B, H, W, C, _stream()))
+    return (ab, ba) if both_orders else ab
+
+
 # --------------------------------------------------------------------------- gradients (ops.py:80-104)
 class _Correlation(torch.autograd.Function):
     @staticmethod

@@ -11,6 +11,7 @@ import torch
 
 from . import _lib
 from .losses import DeferredReductions, compute_losses_parts, compute_losses_stacked
+from .ops import downsample_pyramid
 from .util import downsample
 
 # unsupervised.py:10
@@ -49,7 +50,7 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
         images = (im1_norm, im2_norm, border_mask)
     else:
         levels, top_scale = _LEVELS, FLOW_SCALE                                # :97-103
-        images = tuple(downsample(t, 4) for t in (im1_norm, im2_norm, border_mask))
+        images = None                                                          # made below: chain or one launch
     n_levels = len(flows_fw) if params.get('pyramid_loss') else 1             # :110-113
     # TF1 only runs what the fetched scalar needs: terms without a weight are never evaluated
     weights = {name: params[name + '_weight'] for name in LOSSES if params.get(name + '_weight')}
@@ -69,6 +70,20 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     scaled = _scale_all(scales[:stack_from] * 2, list(flows_fw[:stack_from]) + list(flows_bw[:stack_from])) if stack_from else []
     scaled_fw, scaled_bw = scaled[:stack_from], scaled[stack_from:]
     n_st = n_levels - stack_from
+    # The default pyramid with every level stacked takes its whole image chain (:97-103, :143-145) from ONE launch per
+    # tensor pair (ops.downsample_pyramid: the chain's values bit for bit, written as [im1; im2], [im2; im1] and the mask
+    # twice) instead of three downsample launches per level and three concatenations.
+    chain = None
+    if images is None:
+        _, H, W, _ = im1_norm.shape
+        step = 4 << (n_levels - 1)
+        if (stack_from == 0 and n_levels <= 5 and H % step == 0 and W % step == 0 and im1_norm.shape[3] == 3
+                and border_mask.shape[3] == 1 and 2 * im1_norm.shape[0] <= 65535):
+            i12, i21 = downsample_pyramid(im1_norm, im2_norm, n_levels, both_orders=True)
+            mm = downsample_pyramid(border_mask, border_mask, n_levels)
+            chain = list(zip(i12, i21, mm))
+        else:
+            images = tuple(downsample(t, 4) for t in (im1_norm, im2_norm, border_mask))
     if n_st:
         st = _ScaleStack.apply([float(x) for x in scales[stack_from:]],
                                *(list(flows_fw[stack_from:n_levels]) + list(flows_bw[stack_from:n_levels])))
@@ -90,7 +105,9 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     with DeferredReductions(im1_norm.device) as deferred:
         for i in range(n_levels):
             layer_weight, patch_distance = levels[i]
-            if i == stack_from:
+            if chain is not None:
+                images = chain[i]
+            elif i == stack_from:
                 im1_s, im2_s, mask_s = images
                 images = (torch.cat((im1_s, im2_s)), torch.cat((im2_s, im1_s)), torch.cat((mask_s, mask_s)))
             im1_s, im2_s, mask_s = images
@@ -110,7 +127,7 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
                     scalars.append(part)
                     coeffs.append(layer_weight * weight)
                     owners.append((name, layer_weight))
-            if i + 1 < n_levels:   # the reference also shrinks after the last level; that result is unused
+            if i + 1 < n_levels and chain is None:   # the reference also shrinks after the last level; that result is unused
                 images = tuple(downsample(t, 2) for t in images)                   # :143-145
     if not scalars:
         zero = torch.zeros((), device=im1_norm.device)
