@@ -445,6 +445,9 @@ def test_downsample_pyramid_is_the_chain_bit_for_bit(dev, B, H, W, C, levels):
         assert one[l].shape == ca[l].shape and torch.equal(one[l], ca[l]), l
         assert torch.equal(ab[l], torch.cat((ca[l], cb[l]))), l
         assert torch.equal(ab2[l], ab[l]) and torch.equal(ba2[l], torch.cat((cb[l], ca[l]))), l
+    aa = ops.downsample_pyramid(a, a, levels)              # one tensor twice: read once, both halves written
+    for l in range(levels):
+        assert torch.equal(aa[l], torch.cat((ca[l], ca[l]))), l
     with pytest.raises(ValueError, match="divisible by scale"):
         ops.downsample_pyramid(torch.zeros((1, 8 << levels, (4 << levels) - 4, C), device=dev), None, levels + 1 if levels < 5 else 5)
     with pytest.raises(ValueError, match="both_orders"):

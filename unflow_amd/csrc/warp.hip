@@ -1056,30 +1056,43 @@ constexpr int kPyrLevels = 5, kPyrBlock = 64, kPyrStrip = 16;
 struct PyrArgs {
   const float *src[2];
   float *ab[kPyrLevels], *ba[kPyrLevels];
+  int dup;            // the two sources are one tensor: read it once, write both halves of ab
 };
 template <int C>
 __global__ __launch_bounds__(256) void downsample_pyramid_kernel(PyrArgs a, int levels, int B, int H, int W) {
   __shared__ __attribute__((aligned(16))) float strip[kPyrStrip * kPyrBlock * C];
   __shared__ float lv[16 * 16 * C + 8 * 8 * C + 4 * 4 * C + 2 * 2 * C];
-  const int which = blockIdx.z / B, b = blockIdx.z % B;
+  const int which = blockIdx.z / B, b = blockIdx.z % B;      // (a launch over ONE source that is both a and b has z < B)
+  const bool twice = a.dup != 0;
   const float *src = a.src[which] + (long long)b * H * W * C;
   const int x0 = blockIdx.x * kPyrBlock, y0 = blockIdx.y * kPyrBlock;
   const int H0 = H / 4, W0 = W / 4;
   const long long item_ab = (long long)which * B + b, item_ba = (long long)(1 - which) * B + b;
   constexpr int kRowF4 = kPyrBlock * C / 4;                  // 16-byte pieces of a block row
   const int row_floats = min(kPyrBlock, W - x0) * C;         // W % 4 == 0: whole pieces
-  for (int st = 0; st < kPyrBlock / kPyrStrip; ++st) {
-    __syncthreads();                                         // the previous strip has been consumed
-    for (int i = threadIdx.x; i < kPyrStrip * kRowF4; i += 256) {
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  constexpr int kPieces = kPyrStrip * kRowF4, kPerThread = (kPieces + 255) / 256;
+  f4_t held[kPerThread];                                     // the next strip, in flight while this one is summed
+  auto fetch = [&](int st) {
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k) {
+      const int i = threadIdx.x + k * 256;
       const int r = i / kRowF4, q = i - r * kRowF4;
       const int y = y0 + st * kPyrStrip + r;
-      typedef float f4_t __attribute__((ext_vector_type(4)));
       f4_t v = {0.f, 0.f, 0.f, 0.f};
-      if (y < H && q * 4 < row_floats)
+      if (i < kPieces && y < H && q * 4 < row_floats)
         v = __builtin_nontemporal_load(reinterpret_cast<const f4_t *>(src + ((long long)y * W + x0) * C) + q);
-      reinterpret_cast<f4_t *>(strip)[i] = v;
+      held[k] = v;
     }
+  };
+  fetch(0);
+  for (int st = 0; st < kPyrBlock / kPyrStrip; ++st) {
+    __syncthreads();                                         // the previous strip has been consumed
+#pragma unroll
+    for (int k = 0; k < kPerThread; ++k)
+      if (threadIdx.x + k * 256 < kPieces) reinterpret_cast<f4_t *>(strip)[threadIdx.x + k * 256] = held[k];
     __syncthreads();
+    if (st + 1 < kPyrBlock / kPyrStrip) fetch(st + 1);
     for (int o = threadIdx.x; o < 4 * 16 * C; o += 256) {    // 4 rows x 16 pixels x C of level 0
       const int c = o % C, px = (o / C) % 16, py = o / (16 * C);
       float sum = 0.f;
@@ -1095,6 +1108,7 @@ __global__ __launch_bounds__(256) void downsample_pyramid_kernel(PyrArgs a, int 
         const long long at = ((long long)gy * W0 + gx) * C + c, per = (long long)H0 * W0 * C;
         a.ab[0][item_ab * per + at] = v;
         if (a.ba[0]) a.ba[0][item_ba * per + at] = v;
+        if (twice) a.ab[0][(item_ab + B) * per + at] = v;
       }
     }
   }
@@ -1118,6 +1132,7 @@ __global__ __launch_bounds__(256) void downsample_pyramid_kernel(PyrArgs a, int 
         const long long at = ((long long)gy * Wl + gx) * C + c, per = (long long)Hl * Wl * C;
         a.ab[l][item_ab * per + at] = v;
         if (a.ba[l]) a.ba[l][item_ba * per + at] = v;
+        if (twice) a.ab[l][(item_ab + B) * per + at] = v;
       }
     }
     in_off = out_off;
@@ -1627,12 +1642,14 @@ extern "C" int unflow_downsample_pyramid(const float *im_a, const float *im_b, f
   if ((reinterpret_cast<uintptr_t>(im_a) & 15) || (im_b && (reinterpret_cast<uintptr_t>(im_b) & 15)))
     return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: images must be 16-byte aligned");
   if (out_ba && !im_b) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: the second order needs two tensors");
-  const long long nimg = (long long)B * (im_b ? 2 : 1);
+  const bool dup = im_b == im_a && !out_ba;                  // [a; a]: one pass over the tensor, both halves written
+  const long long nimg = (long long)B * ((im_b && !dup) ? 2 : 1);
   if (nimg == 0 || H == 0 || W == 0) return UNFLOW_OK;
   if (nimg > 65535) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "downsample_pyramid: at most 65535 images per launch");
   PyrArgs a;
   a.src[0] = im_a;
   a.src[1] = im_b ? im_b : im_a;
+  a.dup = dup ? 1 : 0;
   for (int l = 0; l < kPyrLevels; ++l) {
     a.ab[l] = l < levels ? out_ab[l] : nullptr;
     a.ba[l] = (out_ba && l < levels) ? out_ba[l] : nullptr;
