@@ -212,6 +212,14 @@ int unflow_fb_occlusion(const float *flow, const float *flow_other_warped, float
  * they may be the same buffer).  Saves the caller the copy of a shared border mask per flow direction and level. */
 int unflow_fb_occlusion_masked(const float *flow, const float *flow_other_warped, float *flow_diff, float *occ,
                                const float *mask_in, float *mask_out, int B, int H, int W, unflow_stream_t stream);
+/* The same pass (flow_diff, mask_in, mask_out required) with the two losses that need nothing else (losses.py:57-58,
+ * 62-67):  loss_fb = charbonnier_loss(flow_diff, mask_out) / norm_fb  and  loss_occ = charbonnier_loss(1 - mask_out) /
+ * norm_occ  (norm 0 = the element count).  workspace_*: unflow_reduce_workspace_floats(B, H, W) floats each; the scalars
+ * follow the convention of the other loss entry points (NULL inside an open reduce plan, which gets two entries: fb, occ). */
+int unflow_fb_occlusion_losses(const float *flow, const float *flow_other_warped, float *flow_diff, float *occ,
+                               const float *mask_in, float *mask_out, float *loss_fb, float *workspace_fb,
+                               long long norm_fb, float *loss_occ, float *workspace_occ, long long norm_occ, int B, int H,
+                               int W, unflow_stream_t stream);
 /* The same with flow_other_warped = image_warp(flow_other, flow) (losses.py:38-39) computed on
  * the fly; flow_other_warped (optional output), occ and mask_out may be NULL.
  * mask_out = mask_in * (1 - occ) (losses.py:53-55); mask_in may be the same buffer.

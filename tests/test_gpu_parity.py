@@ -656,7 +656,7 @@ def test_charbonnier_and_masks_vs_oracle(oracle_mod, dev):
             xt = T(x, dev).requires_grad_(True)
             m = None if mask is None else T(mask, dev)
             loss = losses.charbonnier_loss(xt, m, beta=beta)
-            np.testing.assert_allclose(float(loss), oracle_mod.charbonnier_loss(x, mask, beta=beta), rtol=1e-5)
+            np.testing.assert_allclose(float(loss.detach()), oracle_mod.charbonnier_loss(x, mask, beta=beta), rtol=1e-5)
             loss.backward()
             want = oracle_mod.charbonnier_loss_grad(x, mask, beta=beta)
             close(xt.grad, want, 1e-5, 1e-6 * max(1.0, np.abs(want).max()))
@@ -818,7 +818,7 @@ def test_pyramid_loss_kitti_mix_gradient_vs_oracle(oracle_mod, dev, full_res):
 
 
 @pytest.mark.parametrize("mask_occlusion,with_border,terms", [
-    ("fb", True, None), ("disocc", True, None), ("", False, None),
+    ("fb", True, None), ("fb", False, None), ("disocc", True, None), ("", False, None),
     ("fb", True, ("ternary", "smooth_2nd", "occ")), ("fb", False, ("ternary",)), ("", True, ("sym", "photo", "fb"))])
 def test_compute_losses_stacked_equals_the_two_directions(oracle_mod, dev, mask_occlusion, with_border, terms):
     """losses.compute_losses_stacked (both directions of losses.py:16-87 as one batch of 2B: [im1; im2], [im2; im1],
@@ -863,6 +863,50 @@ def test_compute_losses_stacked_equals_the_two_directions(oracle_mod, dev, mask_
             continue
         scale = float(g2.abs().max())
         assert float((g1 - g2).abs().max()) <= 2e-6 * scale
+
+
+def test_fb_occlusion_losses_is_the_three_passes(oracle_mod, dev):
+    """losses.fb_occlusion_losses (occlusion test + the 'fb' and 'occ' scalars from one pass) against fb_occlusion,
+    charbonnier_loss and occ_loss: the flow difference, the occlusion map and the mask bit for bit, the scalars to 2e-6
+    (their partial sums are grouped differently); immediate and inside DeferredReductions; the gradient of the given
+    value is charbonnier's."""
+    from unflow_amd import losses
+    rng = np.random.default_rng(5)
+    B, H, W = 2, 33, 50
+    f = T((rng.standard_normal((B, H, W, 2)) * 2).astype(np.float32), dev)
+    w = T((-N(f) + rng.standard_normal((B, H, W, 2)) * 0.8).astype(np.float32), dev)
+    m_in = T((rng.uniform(size=(B, H, W, 1)) > 0.2).astype(np.float32), dev)
+    npx = B * H * W
+    m_ref = torch.empty_like(m_in)
+    d_ref, o_ref = losses.fb_occlusion(f, w, m_ref, mask_in=m_in)
+    x = d_ref.clone().requires_grad_(True)
+    l_fb_ref = losses.charbonnier_loss(x, m_ref, norm_count=npx * 2)
+    l_occ_ref = losses.occ_loss(m_ref, norm_count=npx)
+    l_fb_ref.backward()
+    m_out = torch.empty_like(m_in)
+    d, o, l_fb, l_occ = losses.fb_occlusion_losses(f, w, m_in, m_out, norm_fb=npx * 2, norm_occ=npx)
+    assert torch.equal(d, d_ref) and torch.equal(o, o_ref) and torch.equal(m_out, m_ref)
+    assert 0.0 < float(o.mean()) < 1.0
+    np.testing.assert_allclose(float(l_fb), float(l_fb_ref.detach()), rtol=2e-6)
+    np.testing.assert_allclose(float(l_occ), float(l_occ_ref), rtol=2e-6)
+    x2 = d.clone().requires_grad_(True)
+    losses._CharbonnierGiven.apply(x2, m_out, l_fb, npx * 2).backward()
+    assert torch.equal(x2.grad, x.grad)
+    # in place (mask_in is mask_out) and deferred: the two scalars are the plan's last two entries
+    m_io = m_in.clone()
+    with losses.DeferredReductions(dev) as plan:
+        before = losses.occ_loss(m_ref, norm_count=npx)                       # an entry in front of the pair
+        _, _, l_fb_d, l_occ_d = losses.fb_occlusion_losses(f, w, m_io, m_io, norm_fb=npx * 2, norm_occ=npx)
+        n = plan.plan.n
+        assert n == 3 and l_fb_d.storage_offset() == 1 and l_occ_d.storage_offset() == 2
+        total = torch.empty((), device=dev)
+        sums = torch.empty(8, device=dev)
+        plan.fold([0.0, 1.0, 10.0], [-1, -1, -1], [0.0, 0.0, 0.0], total, sums)
+    assert torch.equal(m_io, m_ref)
+    np.testing.assert_allclose(float(l_fb_d), float(l_fb), rtol=1e-6)
+    np.testing.assert_allclose(float(l_occ_d), float(l_occ), rtol=1e-6)
+    np.testing.assert_allclose(float(before), float(l_occ_ref), rtol=1e-6)
+    np.testing.assert_allclose(float(total), float(l_fb) + 10.0 * float(l_occ), rtol=1e-6)
 
 
 def test_pyramid_loss_stacked_levels_equal_the_unstacked(dev):

@@ -691,6 +691,38 @@ __global__ __launch_bounds__(256) void fb_occlusion_kernel(const float2 *__restr
   }
 }
 
+// The same pass with the two scalars that only need what it has in registers (losses.py:57-58, 62-67):
+//   'fb'  = charbonnier_loss(flow_diff, mask)   and   'occ' = charbonnier_loss(1 - mask)
+// with mask = mask_in * (1 - occ) -- the per-workgroup partial sums of both, instead of two more passes over the
+// difference and the mask (a loss pyramid's coarse levels are bound by their launch count).
+__global__ __launch_bounds__(256) void fb_occlusion_losses_kernel(const float2 *__restrict__ flow,
+                                                                  const float2 *__restrict__ other,
+                                                                  float2 *__restrict__ flow_diff, float *__restrict__ occ,
+                                                                  const float *mask_in, float *mask_out,
+                                                                  float *__restrict__ partial_fb,
+                                                                  float *__restrict__ partial_occ, long long n) {
+  float s_fb = 0.f, s_occ = 0.f;
+  for (long long p = blockIdx.x * 256LL + threadIdx.x; p < n; p += (long long)gridDim.x * 256) {
+    float du, dv;
+    const float o = fb_occluded(flow[p], other[p], other[p], du, dv);
+    const float m = mask_in[p] * (1.f - o);
+    flow_diff[p] = make_float2(du, dv);
+    if (occ) occ[p] = o;
+    mask_out[p] = m;
+    s_fb += charbonnier_term(du, m, kAlpha, 1.f, kEps, 0.f);
+    s_fb += charbonnier_term(dv, m, kAlpha, 1.f, kEps, 0.f);
+    s_occ += charbonnier_term(1.f - m, 1.f, kAlpha, 1.f, kEps, 0.f);
+  }
+  __shared__ float red[4];
+  s_fb = block_sum<256>(s_fb, red);
+  __syncthreads();
+  s_occ = block_sum<256>(s_occ, red);
+  if (threadIdx.x == 0) {
+    partial_fb[blockIdx.x] = s_fb;
+    partial_occ[blockIdx.x] = s_occ;
+  }
+}
+
 // The same with flow_other_warped = image_warp(flow_other, flow) computed on the fly
 // (core/image_warp.py order of operations, as image_warp_fwd_kernel<2>): when only the
 // occlusion mask is wanted the warped flow never goes to HBM (52 -> 24 B/pixel).
@@ -1142,6 +1174,29 @@ extern "C" int unflow_fb_occlusion_masked(const float *flow, const float *flow_o
                      reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other_warped),
                      reinterpret_cast<float2 *>(flow_diff), occ, mask_in, mask_out, n);
   return launch_status("fb_occlusion");
+}
+
+extern "C" int unflow_fb_occlusion_losses(const float *flow, const float *flow_other_warped, float *flow_diff, float *occ,
+                                          const float *mask_in, float *mask_out, float *loss_fb, float *workspace_fb,
+                                          long long norm_fb, float *loss_occ, float *workspace_occ, long long norm_occ,
+                                          int B, int H, int W, unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (n < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion: negative dimension");
+  if (!flow_diff || !mask_in || !mask_out || !workspace_fb || !workspace_occ)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_losses: flow_diff, the masks and the two workspaces are required");
+  hipStream_t s = as_stream(stream);
+  if (n == 0) {
+    if (int rc = zero_loss(loss_fb, "fb_occlusion_losses", s)) return rc;
+    return zero_loss(loss_occ, "fb_occlusion_losses", s);
+  }
+  const unsigned grid = ew_grid(n);
+  hipLaunchKernelGGL(fb_occlusion_losses_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float2 *>(flow),
+                     reinterpret_cast<const float2 *>(flow_other_warped), reinterpret_cast<float2 *>(flow_diff), occ,
+                     mask_in, mask_out, workspace_fb, workspace_occ, n);
+  if (int rc = launch_status("fb_occlusion_losses")) return rc;
+  // (two entries of an open reduce plan, in this order; otherwise two one-block reductions)
+  if (int rc = reduce_partials(workspace_fb, (int)grid, 1.0 / (norm_fb > 0 ? (double)norm_fb : (double)(2 * n)), loss_fb, s)) return rc;
+  return reduce_partials(workspace_occ, (int)grid, 1.0 / (norm_occ > 0 ? (double)norm_occ : (double)n), loss_occ, s);
 }
 
 extern "C" int unflow_charbonnier_fwd(const float *x, const float *mask, int mask_channels, float *loss,

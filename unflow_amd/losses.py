@@ -59,9 +59,10 @@ class DeferredReductions:
         _lib.load().unflow_reduce_plan_end()
         return False
 
-    def last(self, ws):
+    def last(self, ws, back=0):
+        """The scalar of the plan's last entry (``back`` = 1: the one before it), keeping its workspace alive."""
         self.keep.append(ws)
-        return self.results[self.plan.n - 1]
+        return self.results[self.plan.n - 1 - back]
 
     def fold(self, coeff, term, term_weight, total, per_term):
         """results[0..n) <- the deferred reductions; total <- sum coeff[i] results[i]; per_term[t] <- sum over the
@@ -175,6 +176,51 @@ def fb_occlusion(flow, flow_other_warped, mask_inout=None, mask_in=None):
             _lib.check(_lib.load().unflow_fb_occlusion(_ptr(flow), _ptr(other), _ptr(diff), _ptr(occ),
                                                        _ptr(mask_inout), B, H, W, _stream()))
     return diff, occ
+
+
+def fb_occlusion_losses(flow, flow_other_warped, mask_in, mask_out, norm_fb=0, norm_occ=0):
+    """``fb_occlusion`` with ``mask_out = mask_in * (1 - occ)`` and, from the same pass, the two scalars that need
+    nothing else (losses.py:57-58, 62-67): ``charbonnier_loss(flow_diff, mask_out)`` and ``charbonnier_loss(1 - mask_out)``
+    (extension: one launch instead of three).  Returns (flow_diff, occ, loss_fb, loss_occ), all detached -- wrap
+    ``loss_fb`` with ``_CharbonnierGiven`` for its gradient."""
+    flow = _dev(flow.detach(), "flow")
+    other = _dev(flow_other_warped.detach(), "flow_other_warped")
+    _check_flow(None, flow)
+    B, H, W, _ = flow.shape
+    diff = torch.empty_like(flow)
+    occ = torch.empty((B, H, W, 1), device=flow.device, dtype=torch.float32)
+    l_fb, l_occ = _loss_out(flow.device), _loss_out(flow.device)
+    ws_fb, ws_occ = _workspace(B, H, W, flow.device), _workspace(B, H, W, flow.device)
+    with _on(flow.device):
+        _lib.check(_lib.load().unflow_fb_occlusion_losses(
+            _ptr(flow), _ptr(other), _ptr(diff), _ptr(occ), _ptr(_dev(mask_in, "mask_in")), _ptr(mask_out),
+            _ptr(l_fb), _ptr(ws_fb), int(norm_fb), _ptr(l_occ), _ptr(ws_occ), int(norm_occ), B, H, W, _stream()))
+    d = DeferredReductions.current()
+    if d is not None:          # the plan's last two entries: fb, occ
+        l_fb, l_occ = d.last(ws_fb, back=1), d.last(ws_occ)
+    return diff, occ, l_fb, l_occ
+
+
+class _CharbonnierGiven(torch.autograd.Function):
+    """``charbonnier_loss(x, mask)`` (default alpha, beta, epsilon) whose VALUE another kernel has already computed
+    (``fb_occlusion_losses``); the gradient is the ordinary one."""
+
+    @staticmethod
+    def forward(ctx, x, mask, value, norm_count):
+        ctx.save_for_backward(x, mask)
+        ctx.norm_count = norm_count
+        return value.view_as(value)          # (a view: the slot of a deferred reduction is found by its storage offset)
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, mask = ctx.saved_tensors
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        with _on(x.device):
+            _lib.check(_lib.load().unflow_charbonnier_bwd(
+                _ptr(x), _ptr(mask), mask.shape[3], _ptr(gout.contiguous()), _ptr(dx), B, H, W, C, 0.45, 1.0, 0.001,
+                0.0, ctx.norm_count, _stream()))
+        return dx, None, None, None
 
 
 def fb_occlusion_warp(flow, flow_other, mask_inout=None, want_warped=False, unwarped_magnitude=False,
@@ -660,8 +706,13 @@ def _direction_losses(im_a, im_b, fa, other_img, flow, flow_other, border_mask, 
     else:
         mask = border_mask.clone()
 
-    flow_other_warped = fb_occ = diff = None
-    if want('fb') or return_aux:
+    flow_other_warped = fb_occ = diff = fb_value = occ_value = None
+    if want('fb') and want('occ') and mask_occlusion == 'fb' and not return_aux:
+        # the occlusion pass has the flow difference and the final mask in registers: both scalars come out of it
+        flow_other_warped = image_warp(other_img, fa[3])
+        diff, fb_occ, fb_value, occ_value = fb_occlusion_losses(
+            flow, flow_other_warped, border_mask if border_mask is not None else mask, mask, norm_fb=npx * 2, norm_occ=npx)
+    elif want('fb') or return_aux:
         flow_other_warped = image_warp(other_img, fa[3])
         fb = mask_occlusion == 'fb'
         diff, fb_occ = fb_occlusion(flow, flow_other_warped, mask if fb else None, mask_in=border_mask if fb else None)
@@ -673,7 +724,7 @@ def _direction_losses(im_a, im_b, fa, other_img, flow, flow_other, border_mask, 
     if want('sym'):
         losses['sym'] = sym_loss(mask, dens_other, norm_count=npx)
     if want('occ'):      # charbonnier_loss(1 - mask), the complement taken inside the kernel
-        losses['occ'] = occ_loss(mask, norm_count=npx)
+        losses['occ'] = occ_value if occ_value is not None else occ_loss(mask, norm_count=npx)
     if want('photo'):
         losses['photo'] = charbonnier_loss(im_a - b_warped, mask, beta=255, norm_count=npx * 3)
     if want('grad'):
@@ -683,7 +734,9 @@ def _direction_losses(im_a, im_b, fa, other_img, flow, flow_other, border_mask, 
     if want('smooth_2nd'):
         losses['smooth_2nd'] = second_order_loss(fa[2], norm_count=npx * 4)
     if want('fb'):       # flow + warped other flow: the sum the occlusion kernel already wrote (same rounding)
-        losses['fb'] = charbonnier_loss(_FlowDiff.apply(fa[5], flow_other_warped, diff), mask, norm_count=npx * 2)
+        fdiff = _FlowDiff.apply(fa[5], flow_other_warped, diff)
+        losses['fb'] = (_CharbonnierGiven.apply(fdiff, mask, fb_value, npx * 2) if fb_value is not None
+                        else charbonnier_loss(fdiff, mask, norm_count=npx * 2))
     if want('ternary') and b_warped is None:
         losses['ternary'] = ternary_loss_warped(im_a, im_b, fa[0], mask, max_distance=data_max_distance, norm_count=npx)
     elif want('ternary'):
