@@ -228,6 +228,12 @@ int unflow_fb_occlusion_losses(const float *flow, const float *flow_other_warped
 int unflow_fb_occlusion_warp(const float *flow, const float *flow_other, float *flow_other_warped,
                              float *occ, const float *mask_in, float *mask_out, int B, int H,
                              int W, int unwarped_magnitude, unflow_stream_t stream);
+/* unflow_fb_occlusion_losses with flow_other_warped = image_warp(flow_other, flow) computed on the fly (never written):
+ * warp, occlusion test, mask product and the two scalars in one launch. */
+int unflow_fb_occlusion_warp_losses(const float *flow, const float *flow_other, float *flow_diff, float *occ,
+                                    const float *mask_in, float *mask_out, float *loss_fb, float *workspace_fb,
+                                    long long norm_fb, float *loss_occ, float *workspace_occ, long long norm_occ, int B,
+                                    int H, int W, unflow_stream_t stream);
 /* One direction of losses['sym'] (losses.py:27-29,57-61): charbonnier_loss((1 - mask) -
  * cast(density < thresh)), density = forward_warp of the other flow; mask, density
  * [B,H,W,1].  No gradient (both operands are thresholded maps).  norm_count 0 = B*H*W. */

@@ -892,6 +892,24 @@ def test_fb_occlusion_losses_is_the_three_passes(oracle_mod, dev):
     x2 = d.clone().requires_grad_(True)
     losses._CharbonnierGiven.apply(x2, m_out, l_fb, npx * 2).backward()
     assert torch.equal(x2.grad, x.grad)
+    # the other flow warped on the fly (image_warp(flow_other, flow) never written): same difference, map and mask as the
+    # two passes, and _FlowDiffWarp's gradient is image_warp's
+    from unflow_amd.image_warp import image_warp
+    fo = T((-N(f) + rng.standard_normal((B, H, W, 2)) * 0.8).astype(np.float32), dev)
+    fo_a, f_a = fo.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    w_a = image_warp(fo_a, f_a)
+    m_w_ref = torch.empty_like(m_in)
+    d_w_ref, o_w_ref = losses.fb_occlusion(f, w_a, m_w_ref, mask_in=m_in)
+    m_w = torch.empty_like(m_in)
+    d_w, o_w, l_fb_w, l_occ_w = losses.fb_occlusion_losses(f, fo, m_in, m_w, norm_fb=npx * 2, norm_occ=npx, warp_other=True)
+    assert torch.equal(d_w, d_w_ref) and torch.equal(o_w, o_w_ref) and torch.equal(m_w, m_w_ref)
+    np.testing.assert_allclose(float(l_occ_w), float(losses.occ_loss(m_w_ref, norm_count=npx)), rtol=2e-6)
+    up = torch.randn_like(f)
+    (losses._FlowDiff.apply(f_a, w_a, d_w_ref) * up).sum().backward()
+    fo_b, f_b, f_c = fo.clone().requires_grad_(True), f.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    (losses._FlowDiffWarp.apply(f_c, fo_b, f_b, d_w) * up).sum().backward()
+    assert float((fo_b.grad - fo_a.grad).abs().max()) <= 1e-6 * float(fo_a.grad.abs().max())      # (a float-atomic scatter)
+    assert torch.equal(f_b.grad + f_c.grad, f_a.grad) or float((f_b.grad + f_c.grad - f_a.grad).abs().max()) <= 1e-6 * float(f_a.grad.abs().max())
     # in place (mask_in is mask_out) and deferred: the two scalars are the plan's last two entries
     m_io = m_in.clone()
     with losses.DeferredReductions(dev) as plan:

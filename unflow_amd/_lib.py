@@ -54,6 +54,7 @@ SIGNATURES = {
     "unflow_fb_occlusion": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "unflow_fb_occlusion_masked": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "unflow_fb_occlusion_losses": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P, _LL, _I, _I, _I, _P]),
+    "unflow_fb_occlusion_warp_losses": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _LL, _P, _P, _LL, _I, _I, _I, _P]),
     "unflow_fb_occlusion_warp": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "unflow_sym_loss_fwd": (_I, [_P, _P, _F, _P, _P, _I, _I, _I, _LL, _P]),
     "unflow_charbonnier_fwd": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _LL, _P]),

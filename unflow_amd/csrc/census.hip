@@ -726,12 +726,18 @@ __global__ __launch_bounds__(256) void fb_occlusion_losses_kernel(const float2 *
 // The same with flow_other_warped = image_warp(flow_other, flow) computed on the fly
 // (core/image_warp.py order of operations, as image_warp_fwd_kernel<2>): when only the
 // occlusion mask is wanted the warped flow never goes to HBM (52 -> 24 B/pixel).
+// LOSSES: the flow difference is written too and the 'fb' / 'occ' partial sums of fb_occlusion_losses_kernel are left behind.
+template <bool LOSSES>
 __global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__restrict__ flow,
                                                                 const float2 *__restrict__ flow_other,
                                                                 float2 *__restrict__ warped_out,
                                                                 float *__restrict__ occ,
                                                                 const float *mask_in, float *mask_out, int H,
-                                                                int W, int unwarped_magnitude, long long n) {
+                                                                int W, int unwarped_magnitude, long long n,
+                                                                float2 *__restrict__ diff_out,
+                                                                float *__restrict__ partial_fb,
+                                                                float *__restrict__ partial_occ) {
+  float s_fb = 0.f, s_occ = 0.f;
   for (long long v = blockIdx.x * 256LL + threadIdx.x; v < n; v += (long long)gridDim.x * 256) {
     const TiledPixel tp = tiled_pixel(v, H, W);   // n = tiled_total(B, H, W): 64x4 pixel tiles
     if (!tp.ok) continue;
@@ -750,7 +756,26 @@ __global__ __launch_bounds__(256) void fb_occlusion_warp_kernel(const float2 *__
     const float o = fb_occluded(f, w, unwarped_magnitude ? flow_other[p] : w, du, dv);
     if (warped_out) warped_out[p] = w;
     if (occ) occ[p] = o;
-    if (mask_out) mask_out[p] = mask_in[p] * (1.f - o);     // mask_in may be mask_out (in place)
+    if constexpr (LOSSES) {
+      const float m = mask_in[p] * (1.f - o);
+      mask_out[p] = m;
+      diff_out[p] = make_float2(du, dv);
+      s_fb += charbonnier_term(du, m, kAlpha, 1.f, kEps, 0.f);
+      s_fb += charbonnier_term(dv, m, kAlpha, 1.f, kEps, 0.f);
+      s_occ += charbonnier_term(1.f - m, 1.f, kAlpha, 1.f, kEps, 0.f);
+    } else {
+      if (mask_out) mask_out[p] = mask_in[p] * (1.f - o);     // mask_in may be mask_out (in place)
+    }
+  }
+  if constexpr (LOSSES) {
+    __shared__ float red[4];
+    s_fb = block_sum<256>(s_fb, red);
+    __syncthreads();
+    s_occ = block_sum<256>(s_occ, red);
+    if (threadIdx.x == 0) {
+      partial_fb[blockIdx.x] = s_fb;
+      partial_occ[blockIdx.x] = s_occ;
+    }
   }
 }
 
@@ -1279,10 +1304,35 @@ extern "C" int unflow_fb_occlusion_warp(const float *flow, const float *flow_oth
     return launch_status("fb_occlusion_warp");
   }
   const long long vn = tiled_total(B, H, W);
-  hipLaunchKernelGGL(fb_occlusion_warp_kernel, dim3(ew_grid(vn)), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(fb_occlusion_warp_kernel<false>, dim3(ew_grid(vn)), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const float2 *>(flow), reinterpret_cast<const float2 *>(flow_other),
-                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_in, mask_out, H, W, unwarped_magnitude, vn);
+                     reinterpret_cast<float2 *>(flow_other_warped), occ, mask_in, mask_out, H, W, unwarped_magnitude, vn,
+                     (float2 *)nullptr, (float *)nullptr, (float *)nullptr);
   return launch_status("fb_occlusion_warp");
+}
+
+extern "C" int unflow_fb_occlusion_warp_losses(const float *flow, const float *flow_other, float *flow_diff, float *occ,
+                                               const float *mask_in, float *mask_out, float *loss_fb,
+                                               float *workspace_fb, long long norm_fb, float *loss_occ,
+                                               float *workspace_occ, long long norm_occ, int B, int H, int W,
+                                               unflow_stream_t stream) {
+  const long long n = (long long)B * H * W;
+  if (B < 0 || H < 0 || W < 0) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp: negative dimension");
+  if (!flow_diff || !mask_in || !mask_out || !workspace_fb || !workspace_occ)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "fb_occlusion_warp_losses: flow_diff, the masks and the two workspaces are required");
+  hipStream_t s = as_stream(stream);
+  if (n == 0) {
+    if (int rc = zero_loss(loss_fb, "fb_occlusion_warp_losses", s)) return rc;
+    return zero_loss(loss_occ, "fb_occlusion_warp_losses", s);
+  }
+  const long long vn = tiled_total(B, H, W);
+  const unsigned grid = ew_grid(vn);
+  hipLaunchKernelGGL(fb_occlusion_warp_kernel<true>, dim3(grid), dim3(256), 0, s, reinterpret_cast<const float2 *>(flow),
+                     reinterpret_cast<const float2 *>(flow_other), (float2 *)nullptr, occ, mask_in, mask_out, H, W, 0, vn,
+                     reinterpret_cast<float2 *>(flow_diff), workspace_fb, workspace_occ);
+  if (int rc = launch_status("fb_occlusion_warp_losses")) return rc;
+  if (int rc = reduce_partials(workspace_fb, (int)grid, 1.0 / (norm_fb > 0 ? (double)norm_fb : (double)(2 * n)), loss_fb, s)) return rc;
+  return reduce_partials(workspace_occ, (int)grid, 1.0 / (norm_occ > 0 ? (double)norm_occ : (double)n), loss_occ, s);
 }
 
 extern "C" int unflow_sym_loss_fwd(const float *mask, const float *density, float thresh, float *loss,

@@ -16,7 +16,7 @@ import threading
 import torch
 
 from . import _lib
-from .image_warp import image_warp
+from .image_warp import image_warp, image_warp_grad
 from .ops import _check_flow, _dev, _on, _ptr, _require_rank4, _stream, forward_warp
 
 DISOCC_THRESH = 0.8  # losses.py:9
@@ -178,11 +178,13 @@ def fb_occlusion(flow, flow_other_warped, mask_inout=None, mask_in=None):
     return diff, occ
 
 
-def fb_occlusion_losses(flow, flow_other_warped, mask_in, mask_out, norm_fb=0, norm_occ=0):
+def fb_occlusion_losses(flow, flow_other_warped, mask_in, mask_out, norm_fb=0, norm_occ=0, warp_other=False):
     """``fb_occlusion`` with ``mask_out = mask_in * (1 - occ)`` and, from the same pass, the two scalars that need
     nothing else (losses.py:57-58, 62-67): ``charbonnier_loss(flow_diff, mask_out)`` and ``charbonnier_loss(1 - mask_out)``
     (extension: one launch instead of three).  Returns (flow_diff, occ, loss_fb, loss_occ), all detached -- wrap
-    ``loss_fb`` with ``_CharbonnierGiven`` for its gradient."""
+    ``loss_fb`` with ``_CharbonnierGiven`` for its gradient.  ``warp_other``: the second argument is the other
+    direction's flow itself and ``image_warp(flow_other, flow)`` is taken on the fly (one launch instead of four;
+    ``_FlowDiffWarp`` carries the warp's gradient)."""
     flow = _dev(flow.detach(), "flow")
     other = _dev(flow_other_warped.detach(), "flow_other_warped")
     _check_flow(None, flow)
@@ -192,13 +194,30 @@ def fb_occlusion_losses(flow, flow_other_warped, mask_in, mask_out, norm_fb=0, n
     l_fb, l_occ = _loss_out(flow.device), _loss_out(flow.device)
     ws_fb, ws_occ = _workspace(B, H, W, flow.device), _workspace(B, H, W, flow.device)
     with _on(flow.device):
-        _lib.check(_lib.load().unflow_fb_occlusion_losses(
+        fn = _lib.load().unflow_fb_occlusion_warp_losses if warp_other else _lib.load().unflow_fb_occlusion_losses
+        _lib.check(fn(
             _ptr(flow), _ptr(other), _ptr(diff), _ptr(occ), _ptr(_dev(mask_in, "mask_in")), _ptr(mask_out),
             _ptr(l_fb), _ptr(ws_fb), int(norm_fb), _ptr(l_occ), _ptr(ws_occ), int(norm_occ), B, H, W, _stream()))
     d = DeferredReductions.current()
     if d is not None:          # the plan's last two entries: fb, occ
         l_fb, l_occ = d.last(ws_fb, back=1), d.last(ws_occ)
     return diff, occ, l_fb, l_occ
+
+
+class _FlowDiffWarp(torch.autograd.Function):
+    """``flow + image_warp(flow_other, coords)`` (losses.py:38-41) whose value the occlusion kernel has computed on the
+    fly: the gradient goes to ``flow`` unchanged and through ``image_warp``'s backward to ``flow_other`` and ``coords``."""
+
+    @staticmethod
+    def forward(ctx, flow, flow_other, coords, diff):
+        ctx.save_for_backward(flow_other, coords)
+        return diff.view_as(diff)
+
+    @staticmethod
+    def backward(ctx, g):
+        flow_other, coords = ctx.saved_tensors
+        d_other, d_coords = image_warp_grad(g, flow_other, coords, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        return g, d_other, d_coords, None
 
 
 class _CharbonnierGiven(torch.autograd.Function):
@@ -707,11 +726,14 @@ def _direction_losses(im_a, im_b, fa, other_img, flow, flow_other, border_mask, 
         mask = border_mask.clone()
 
     flow_other_warped = fb_occ = diff = fb_value = occ_value = None
+    fdiff = None
     if want('fb') and want('occ') and mask_occlusion == 'fb' and not return_aux:
-        # the occlusion pass has the flow difference and the final mask in registers: both scalars come out of it
-        flow_other_warped = image_warp(other_img, fa[3])
+        # the occlusion pass warps the other flow on the fly and has the flow difference and the final mask in
+        # registers: warp, test, mask and both scalars are one launch
         diff, fb_occ, fb_value, occ_value = fb_occlusion_losses(
-            flow, flow_other_warped, border_mask if border_mask is not None else mask, mask, norm_fb=npx * 2, norm_occ=npx)
+            flow, other_img, border_mask if border_mask is not None else mask, mask, norm_fb=npx * 2, norm_occ=npx,
+            warp_other=True)
+        fdiff = _FlowDiffWarp.apply(fa[5], other_img, fa[3], diff)
     elif want('fb') or return_aux:
         flow_other_warped = image_warp(other_img, fa[3])
         fb = mask_occlusion == 'fb'
@@ -734,7 +756,8 @@ def _direction_losses(im_a, im_b, fa, other_img, flow, flow_other, border_mask, 
     if want('smooth_2nd'):
         losses['smooth_2nd'] = second_order_loss(fa[2], norm_count=npx * 4)
     if want('fb'):       # flow + warped other flow: the sum the occlusion kernel already wrote (same rounding)
-        fdiff = _FlowDiff.apply(fa[5], flow_other_warped, diff)
+        if fdiff is None:
+            fdiff = _FlowDiff.apply(fa[5], flow_other_warped, diff)
         losses['fb'] = (_CharbonnierGiven.apply(fdiff, mask, fb_value, npx * 2) if fb_value is not None
                         else charbonnier_loss(fdiff, mask, norm_count=npx * 2))
     if want('ternary') and b_warped is None:
