@@ -166,6 +166,15 @@ int unflow_reduce_plan_run(const unflow_reduce_plan *plan, const float *coeff, c
 /* out[i] = sum_{k < n} srcs[k][i] for i < count: the gradient contributions of the n consumers of one tensor in ONE
  * launch (an autograd engine issues n - 1 adds).  srcs is a HOST array of n <= 8 device pointers. */
 int unflow_sum_tensors(const float *const *srcs, int n, float *out, long long count, unflow_stream_t stream);
+/* The flow scaling of a loss pyramid (src/e2eflow/core/unsupervised.py:118) for levels that run both directions as one
+ * batch: F[l] = scale[l] * [fw[l]; bw[l]] and G[l] = scale[l] * [bw[l]; fw[l]] (concatenated along the batch) for n <= 8
+ * levels in one launch, and its gradient d_fw[l] = scale[l] * (gF[l][first half] + gG[l][second half]),
+ * d_bw[l] = scale[l] * (gF[l][second half] + gG[l][first half]) (gG, or single entries of it, may be NULL).  All pointer
+ * and count / scale arguments are HOST arrays of n entries; count[l] = floats of ONE direction's [B,h,w,2] tensor. */
+int unflow_scale_stack_fwd(const float *const *fw, const float *const *bw, float *const *F, float *const *G,
+                           const long long *count, const float *scale, int n, unflow_stream_t stream);
+int unflow_scale_stack_bwd(const float *const *gF, const float *const *gG, float *const *d_fw, float *const *d_bw,
+                           const long long *count, const float *scale, int n, unflow_stream_t stream);
 
 int unflow_ternary_loss_fwd(const float *im1, const float *im2_warped, const float *mask,
                             float *loss, float *dldd, float *dist, float *workspace, int B, int H,

@@ -45,6 +45,8 @@ SIGNATURES = {
     "unflow_reduce_plan_end": (_I, []),
     "unflow_reduce_plan_run": (_I, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "unflow_sum_tensors": (_I, [_P, _I, _P, _LL, _P]),
+    "unflow_scale_stack_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "unflow_scale_stack_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "unflow_ternary_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),
     "unflow_ternary_loss_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "unflow_ternary_loss_warp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _P]),

@@ -1008,11 +1008,86 @@ __global__ __launch_bounds__(256) void sum_tensors_kernel(SumArgs a, int n, floa
     out[i] = s;
   }
 }
+// The flow scaling of a loss pyramid whose levels run both directions as one batch (core/unsupervised.py:118):
+//   F_l = s_l * [fw_l; bw_l],  G_l = s_l * [bw_l; fw_l]   ([a; b]: concatenated along the batch)   for all levels in ONE launch,
+// and the gradient   d fw_l = s_l * (gF_l[first half] + gG_l[second half]),  d bw_l = s_l * (gF_l[second] + gG_l[first]).
+// Work is in float2 units (a flow vector); off[] = prefix sums of the levels' vector counts.
+constexpr int kStackLevels = 8;
+struct StackArgs {
+  const float2 *a[kStackLevels], *b[kStackLevels];     // forward: fw, bw;   backward: gF, gG (gG may be null)
+  float2 *x[kStackLevels], *y[kStackLevels];           // forward: F, G;     backward: d_fw, d_bw
+  long long off[kStackLevels + 1];
+  float scale[kStackLevels];
+};
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void scale_stack_kernel(StackArgs a, int n) {
+  const long long total = a.off[n];
+  for (long long t = blockIdx.x * 256LL + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    int l = 0;
+    while (l + 1 < n && t >= a.off[l + 1]) ++l;
+    const long long i = t - a.off[l], cnt = a.off[l + 1] - a.off[l];
+    const float s = a.scale[l];
+    if constexpr (!BACKWARD) {
+      const float2 f = a.a[l][i], b = a.b[l][i];
+      const float2 sf = make_float2(f.x * s, f.y * s), sb = make_float2(b.x * s, b.y * s);
+      a.x[l][i] = sf;
+      a.x[l][cnt + i] = sb;
+      a.y[l][i] = sb;
+      a.y[l][cnt + i] = sf;
+    } else {
+      float2 df = a.a[l][i], db = a.a[l][cnt + i];
+      if (a.b[l]) {
+        const float2 g2 = a.b[l][cnt + i], g1 = a.b[l][i];
+        df = make_float2(df.x + g2.x, df.y + g2.y);
+        db = make_float2(db.x + g1.x, db.y + g1.y);
+      }
+      a.x[l][i] = make_float2(df.x * s, df.y * s);
+      a.y[l][i] = make_float2(db.x * s, db.y * s);
+    }
+  }
+}
 }  // namespace
 
 }  // namespace unflow
 
 using namespace unflow;
+
+static int scale_stack_launch(bool backward, const float *const *a, const float *const *b, float *const *x, float *const *y,
+                              const long long *count, const float *scale, int n, unflow_stream_t stream) {
+  if (!a || !x || !y || !count || !scale || n < 1 || n > kStackLevels)
+    return fail(UNFLOW_ERR_INVALID_ARGUMENT, "scale_stack: 1 to 8 levels");
+  StackArgs args;
+  args.off[0] = 0;
+  for (int l = 0; l < kStackLevels; ++l) {
+    const bool in = l < n;
+    if (in && (count[l] < 0 || (count[l] & 1))) return fail(UNFLOW_ERR_INVALID_ARGUMENT, "scale_stack: counts are floats of [B,h,w,2] tensors");
+    if (in && (!a[l] || !x[l] || !y[l] || (!backward && (!b || !b[l]))))
+      return fail(UNFLOW_ERR_INVALID_ARGUMENT, "scale_stack: null tensor");
+    args.a[l] = in ? reinterpret_cast<const float2 *>(a[l]) : nullptr;
+    args.b[l] = (in && b) ? reinterpret_cast<const float2 *>(b[l]) : nullptr;
+    args.x[l] = in ? reinterpret_cast<float2 *>(x[l]) : nullptr;
+    args.y[l] = in ? reinterpret_cast<float2 *>(y[l]) : nullptr;
+    args.scale[l] = in ? scale[l] : 0.f;
+    args.off[l + 1] = args.off[l] + (in ? count[l] / 2 : 0);
+  }
+  const long long total = args.off[n];
+  if (total == 0) return UNFLOW_OK;
+  const long long blocks = (total + 255) / 256;
+  const dim3 g((unsigned)(blocks < 8192 ? blocks : 8192));
+  if (backward) hipLaunchKernelGGL(scale_stack_kernel<true>, g, dim3(256), 0, as_stream(stream), args, n);
+  else hipLaunchKernelGGL(scale_stack_kernel<false>, g, dim3(256), 0, as_stream(stream), args, n);
+  return launch_status("scale_stack");
+}
+
+extern "C" int unflow_scale_stack_fwd(const float *const *fw, const float *const *bw, float *const *F, float *const *G,
+                                      const long long *count, const float *scale, int n, unflow_stream_t stream) {
+  return scale_stack_launch(false, fw, bw, F, G, count, scale, n, stream);
+}
+
+extern "C" int unflow_scale_stack_bwd(const float *const *gF, const float *const *gG, float *const *d_fw, float *const *d_bw,
+                                      const long long *count, const float *scale, int n, unflow_stream_t stream) {
+  return scale_stack_launch(true, gF, gG, d_fw, d_bw, count, scale, n, stream);
+}
 
 extern "C" size_t unflow_reduce_workspace_floats(int B, int H, int W) {
   // One partial per workgroup: the 32x8 tiles of the tiled loss kernels (census, stencils)

@@ -7,11 +7,13 @@ The network that produces the flow pyramid (``flownet``, :72-79), augmentation
 (:30-62) and the weight-decay term (:147) are outside this path; the caller
 passes the pyramid in and adds its own regularisation loss.
 """
+import ctypes
+
 import torch
 
 from . import _lib
 from .losses import DeferredReductions, compute_losses_parts, compute_losses_stacked
-from .ops import downsample_pyramid
+from .ops import _dev, _on, _stream, downsample_pyramid
 from .util import downsample
 
 # unsupervised.py:10
@@ -198,47 +200,53 @@ class _ScaleAll(torch.autograd.Function):
 
 class _ScaleStack(torch.autograd.Function):
     """For n levels: (fw_i, bw_i) -> F_i = scale_i * [fw_i; bw_i] and G_i = scale_i * [bw_i; fw_i] ([a; b]: along the batch).
-    Two multi-tensor launches for all levels (scale; copy into the halves), two for the gradient (add the two orders'
-    halves; scale) -- against a concatenation, a roll and the roll's gradient per level."""
+    ONE launch for all levels (``unflow_scale_stack_fwd``) and one for the gradient, which adds the two orders' halves and
+    scales (``unflow_scale_stack_bwd``) -- against a concatenation, a roll and the roll's gradient per level."""
 
     @staticmethod
     def forward(ctx, scales, *tensors):
         n = len(scales)
-        ctx.scales = scales
+        tensors = [_dev(t, "flow") for t in tensors]
+        fw, bw = tensors[:n], tensors[n:]
+        for f, b in zip(fw, bw):
+            if f.shape != b.shape or f.dim() != 4 or f.shape[3] != 2:
+                raise ValueError("flow pyramid: [B,h,w,2] tensors, the same shapes in both directions")
+        ctx.scales, ctx.shapes = scales, [tuple(t.shape) for t in fw]
         ctx.set_materialize_grads(False)
-        scaled = torch._foreach_mul(list(tensors), scales + scales)
-        fw, bw = scaled[:n], scaled[n:]
-        B = tensors[0].shape[0]
-        ctx.B = B
+        B = fw[0].shape[0]
         F = [t.new_empty((2 * B,) + tuple(t.shape[1:])) for t in fw]
         G = [t.new_empty((2 * B,) + tuple(t.shape[1:])) for t in fw]
-        torch._foreach_copy_([f[:B] for f in F] + [f[B:] for f in F] + [g[B:] for g in G] + [g[:B] for g in G],
-                             list(fw) + list(bw) + list(fw) + list(bw))
+        with _on(fw[0].device):
+            _lib.check(_lib.load().unflow_scale_stack_fwd(_ptrs(fw), _ptrs(bw), _ptrs(F), _ptrs(G),
+                                                          (ctypes.c_longlong * n)(*[t.numel() for t in fw]),
+                                                          (ctypes.c_float * n)(*scales), n, _stream()))
         return tuple(F) + tuple(G)
 
     @staticmethod
     def backward(ctx, *grads):
-        n, B = len(ctx.scales), ctx.B
-        gF, gG = grads[:n], grads[n:]
+        n = len(ctx.scales)
+        gF, gG = list(grads[:n]), list(grads[n:])
+        live = [i for i in range(n) if gF[i] is not None or gG[i] is not None]
         out = [None] * (2 * n)
-        both = [i for i in range(n) if gF[i] is not None and gG[i] is not None]
-        one = [i for i in range(n) if (gF[i] is None) != (gG[i] is None)]
-        parts, where = [], []
-        if both:      # d fw = F's first half + G's second, d bw = F's second half + G's first
-            a = [gF[i][:B] for i in both] + [gF[i][B:] for i in both]
-            b = [gG[i][B:] for i in both] + [gG[i][:B] for i in both]
-            parts += list(torch._foreach_add(a, b))
-            where += both + [n + i for i in both]
-        for i in one:
-            if gF[i] is not None:
-                parts += [gF[i][:B], gF[i][B:]]
-            else:
-                parts += [gG[i][B:], gG[i][:B]]
-            where += [i, n + i]
-        if parts:
-            for k, g in zip(where, torch._foreach_mul(parts, [ctx.scales[k % n] for k in where])):
-                out[k] = g
+        if live:
+            ref = next(g for g in gF + gG if g is not None)
+            # (a level whose [fw; bw] order received no gradient: its two halves are zero)
+            a = [(gF[i].contiguous() if gF[i] is not None else ref.new_zeros((2 * ctx.shapes[i][0],) + ctx.shapes[i][1:])) for i in live]
+            b = [(gG[i].contiguous() if gG[i] is not None else None) for i in live]
+            d_fw = [ref.new_empty(ctx.shapes[i]) for i in live]
+            d_bw = [ref.new_empty(ctx.shapes[i]) for i in live]
+            m = len(live)
+            with _on(ref.device):
+                _lib.check(_lib.load().unflow_scale_stack_bwd(_ptrs(a), _ptrs(b), _ptrs(d_fw), _ptrs(d_bw),
+                                                              (ctypes.c_longlong * m)(*[t.numel() for t in d_fw]),
+                                                              (ctypes.c_float * m)(*[ctx.scales[i] for i in live]), m, _stream()))
+            for k, i in enumerate(live):
+                out[i], out[n + i] = d_fw[k], d_bw[k]
         return (None,) + tuple(out)
+
+
+def _ptrs(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[(t.data_ptr() if t is not None else None) for t in tensors])
 
 
 def _scale_all(scales, tensors):
