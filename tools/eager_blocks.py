@@ -1,0 +1,13 @@
+import os, sys
+sys.path.insert(0, "/root/repo")
+import torch, bench, time
+wl = bench.Workload(32, torch.device("cuda:0"), seed=1234, global_batch=32, features=False)
+from unflow_amd import unsupervised
+pf, pb = bench.kitti_pyramid_flows(torch, wl.im1.device, 32)
+def step():
+    loss, _ = unsupervised.pyramid_loss(wl.im1, wl.im2, wl.border, pf, pb, bench.KITTI)
+    return (loss,) + torch.autograd.grad(loss, pf + pb)
+for blk in range(6):
+    t0 = time.perf_counter()
+    ms = bench.event_time(torch, step, n=10, warm=0)
+    print("block %d: %.3f ms per step by events, %.3f by the host clock" % (blk, ms, (time.perf_counter() - t0) * 100))
