@@ -1,5 +1,10 @@
+"""The eager KITTI-config pyramid step timed in successive blocks of ten steps, from the first step of the process: shows the one
+slow block early in a process (bench.py times three blocks and reports their minimum).  usage: python tools/eager_blocks.py [nogc]"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if len(sys.argv) > 1 and sys.argv[1] == "nogc":
+    import gc
+    gc.disable()
 import torch, bench, time
 wl = bench.Workload(32, torch.device("cuda:0"), seed=1234, global_batch=32, features=False)
 from unflow_amd import unsupervised
