@@ -469,7 +469,8 @@ def kitti_config_step(wl):
         return (loss,) + torch.autograd.grad(loss, pf + pb)
     # (the first eager steps also fill the caching allocator with the pyramid's temporaries: 5 warm-up steps.  One of the
     # first blocks of ten steps of a process takes 5-9 ms per step on the host side -- tools/eager_blocks.py: 1.9, 8.8, 1.4,
-    # 1.4, 1.4, 1.4 ms -- so three blocks are timed, all of them reported, and the steady state is their minimum.)
+    # 1.4, 1.4, 1.4 ms; it is a full collection of Python's cyclic garbage collector: with gc.disable() every block takes
+    # 1.3 ms -- so three blocks are timed, all of them reported, and the steady state is their minimum.)
     eager_blocks = [event_time(torch, step, n=10, warm=5 if k == 0 else 0) for k in range(3)]
     eager_ms = min(eager_blocks)
     eager = [t.detach().clone() for t in step()]
