@@ -72,6 +72,35 @@ def test_argument_validation_before_any_launch():
         ops.backward_warp([[0.0]], torch.zeros(1, 1, 1, 2))
 
 
+def test_round4_entry_points_validate_on_the_host():
+    """unflow_downsample_pyramid, unflow_scale_stack_* and unflow_fb_occlusion_*losses reject bad arguments before any
+    device work (plain C calls with null / dummy pointers: nothing is launched), with the reference's message where the
+    reference has one (ops/downsample_op.cc:37-40)."""
+    import ctypes
+    from unflow_amd import _lib, ops
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    one = (P * 5)(*[P(16)] * 5)
+    cases = [
+        (lambda: lib.unflow_downsample_pyramid(P(16), None, one, None, 6, 1, 64, 64, 3, None), "1 to 5 levels"),
+        (lambda: lib.unflow_downsample_pyramid(P(16), None, one, None, 2, 1, 64, 64, 2, None), "1 or 3 channels"),
+        (lambda: lib.unflow_downsample_pyramid(P(16), None, one, None, 3, 1, 64, 40, 3, None), "divisible by scale"),
+        (lambda: lib.unflow_downsample_pyramid(P(20), None, one, None, 1, 1, 64, 64, 3, None), "16-byte aligned"),
+        (lambda: lib.unflow_downsample_pyramid(P(16), None, one, one, 1, 1, 64, 64, 3, None), "needs two tensors"),
+        (lambda: lib.unflow_scale_stack_fwd(one, one, one, one, (ctypes.c_longlong * 1)(8), (ctypes.c_float * 1)(1.0), 0, None), "1 to 8 levels"),
+        (lambda: lib.unflow_scale_stack_fwd(one, one, one, one, (ctypes.c_longlong * 1)(7), (ctypes.c_float * 1)(1.0), 1, None), r"\[B,h,w,2\]"),
+        (lambda: lib.unflow_scale_stack_bwd(one, None, one, (P * 1)(None), (ctypes.c_longlong * 1)(8), (ctypes.c_float * 1)(1.0), 1, None), "null tensor"),
+        (lambda: lib.unflow_fb_occlusion_losses(P(16), P(16), None, None, P(16), P(16), None, P(16), 0, None, P(16), 0, 1, 4, 4, None), "are required"),
+        (lambda: lib.unflow_fb_occlusion_warp_losses(P(16), P(16), P(16), None, P(16), P(16), None, None, 0, None, P(16), 0, 1, 4, 4, None), "are required"),
+    ]
+    for call, pattern in cases:
+        with pytest.raises(ValueError, match=pattern):
+            _lib.check(call())
+    assert lib.unflow_downsample_pyramid(P(16), None, one, None, 1, 0, 64, 64, 3, None) == 0        # an empty batch: nothing to do
+    with pytest.raises(RuntimeError, match="no CPU kernels"):
+        ops.downsample_pyramid(torch.zeros(1, 64, 64, 3))
+
+
 def test_missing_library_fails_loudly(tmp_path):
     """Importing works, the first use raises: never a silent fallback."""
     code = (
