@@ -199,7 +199,6 @@ def downsample_pyramid(im_a, im_b=None, levels=5, both_orders=False):
     chain of ``downsample`` calls.  With ``im_b`` the levels are the stacked batches ``[a; b]`` (and, with
     ``both_orders``, also ``[b; a]``) along the batch.  Returns the list of levels (or the two lists).  One or
     three channels, at most five levels, extents divisible by ``4 << (levels - 1)``; not differentiable."""
-    import ctypes
     im_a = _dev(im_a.detach(), "im_a")
     _require_rank4(im_a, "im_a")
     if im_b is not None:

@@ -61,7 +61,7 @@ def pyramid_loss(im1_norm, im2_norm, border_mask, flows_fw, flows_bw, params, no
     # do not fill the chip evaluate both directions as ONE batch of 2B (losses.compute_losses_stacked: the backward
     # direction is the forward direction of B more pairs), half the launches; the pixel count falls from level to level,
     # so these are the levels from `stack_from` on, and their scaled flows come out stacked in both orders
-    # ([fw; bw] and, for the other direction's role, [bw; fw]) from the same pair of launches.
+    # ([fw; bw] and, for the other direction's role, [bw; fw]) from one launch of their own (_ScaleStack).
     scales = [top_scale / (2 ** i) for i in range(n_levels)]
     stack_from = n_levels
     if STACK_DIRECTIONS:
