@@ -710,6 +710,14 @@ def main():
             dt = float(t.item())
         return dt
 
+    # Python's cyclic garbage collector stays out of the timed loops, as in timeit: a full collection is a 40-70 ms pause of
+    # the launching thread (tools/eager_blocks.py), and when it falls into the K timed steps the launch queue drains -- one
+    # run of the round printed 6.08 ms per step with every kernel at its usual duration where the others print 5.36-5.58.
+    # Nothing of the step is skipped: the collector runs right before the region and is switched on again after the loops.
+    import gc
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -752,6 +760,9 @@ def main():
         fence()
         dt_bidir = max_over_ranks(time.perf_counter() - t1)
 
+    if gc_was_enabled:
+        gc.enable()
+
     # in-run check of the fused loss kernels the step times (every rank checks its own shard)
     fused = float(wl.loss_leg()["ternary"].detach())
     composed = float(wl.composed_loss())
@@ -778,6 +789,8 @@ def main():
                        "parallelism": "batch-sharded x%d (one process per GPU), all-reduce of loss + 156.7 MB grad buffer "
                                       "(started behind the second correlation_grad, overlapping the loss leg only)" % world,
                        "world_size": world, "backend": dist.get_backend() if world > 1 else None,
+                       "timing": "K steps between fences (synchronize + barrier); Python's garbage collector runs right before "
+                                 "the region and is off inside it (as in timeit)",
                        **({"step_order": step_order} if world > 1 else {}),
                        **({"rehearsal_all_ranks_on_one_gpu": True} if shared else {})},
             "roofline": {"bound": "mfma",
