@@ -1209,15 +1209,23 @@ __global__ __launch_bounds__(TX * TY) void image_warp_bwd_im_tiled_kernel(const 
 #pragma unroll
     for (int c = 0; c < C; ++c) bad = bad || (live && !(fabsf(g[c]) <= 3.0e38f));
     unsigned gb = bad ? 0x7f800000u : __float_as_uint(gabs);      // non-negative floats order like their bits
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      b0 = min(b0, __shfl_xor(b0, off, 64));
-      b1 = min(b1, __shfl_xor(b1, off, 64));
-      b2 = min(b2, __shfl_xor(b2, off, 64));
-      b3 = min(b3, __shfl_xor(b3, off, 64));
-      gb = max(gb, (unsigned)__shfl_xor((int)gb, off, 64));
-    }
-    if ((threadIdx.x & 63) == 0 && b0 != 0x7fffffff) {
+    // wave reductions on the DPP network (row_shr 1, 2, 4, 8: an inclusive scan of each row of 16 lanes; row_bcast 15 and 31
+    // carry the rows' results on): six vector instructions per value and no LDS traffic, where the xor butterfly is six
+    // ds_bpermute round trips per value (0.330 -> 0.309 ms for three channels, 0.225 -> 0.204 ms for two).  The result is in lane 63.
+    auto red = [](int v, auto op) {
+      v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+      v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+      v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+      v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+      v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1 and 3
+      v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));     // row_bcast:31 into rows 2 and 3
+      return v;
+    };
+    auto imin = [](int a, int b) { return min(a, b); };
+    auto umax = [](int a, int b) { return (int)max((unsigned)a, (unsigned)b); };
+    b0 = red(b0, imin); b1 = red(b1, imin); b2 = red(b2, imin); b3 = red(b3, imin);
+    gb = (unsigned)red((int)gb, umax);
+    if ((threadIdx.x & 63) == 63 && b0 != 0x7fffffff) {
       atomicMin(&box[0], b0);
       atomicMin(&box[1], b1);
       atomicMin(&box[2], b2);
